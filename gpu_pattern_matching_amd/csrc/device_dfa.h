@@ -1,0 +1,32 @@
+// acm_dfa: the device-resident automaton (layout described in device_dfa.hip).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+struct acm_dfa {
+	int device = 0;
+	int num_cus = 256;
+	uint32_t num_states = 0;
+	uint32_t first_final = 0;
+	uint32_t hot_rows = 0;
+	uint32_t max_pattern_len = 0;
+
+	uint32_t *d_cold = nullptr;
+	uint16_t *d_hot = nullptr;
+	int32_t *d_out = nullptr;
+	uint32_t *d_dev2ref = nullptr;
+	uint32_t *d_depth_cum = nullptr;
+	uint16_t *d_depth_final = nullptr;
+	size_t device_bytes = 0;
+
+	std::vector<uint32_t> ref2dev;       // host copies for init_state / last_state
+	std::vector<uint32_t> dev2ref_host;
+
+	int chain_bytes = 0;                 // 0 = pick automatically
+
+	// optional in-line timing (acm_scan_profile_*): event triples
+	// {before walk, after walk, after last kernel} per recorded launch
+	mutable bool profile = false;
+	mutable std::vector<void *> profile_events;
+};

@@ -1,0 +1,425 @@
+/*
+ * acmatch.h -- C ABI of libacmatch.so, the MI355X-native (gfx950, HIP)
+ * Aho-Corasick matcher.
+ *
+ * Two layers live in this one header:
+ *
+ *  (1) acm_*  : the native boundary.  Plain pointers and sizes, explicit
+ *               device pointers + stream, integer status codes.  This is
+ *               what an FFI (ctypes, cgo, JNI) binds, and what bench.py uses.
+ *
+ *  (2) the reference's own names (acsm_*, databuf_*, ocl_aho_match*,
+ *      ocl_prefix_sum*, ocl_compact_array*, ocl_bitonic_sort*, clinitctx):
+ *               same names, arity, argument meaning and error behaviour as
+ *               the OpenCL library they replace, so ocl_worker.c /
+ *               ocl_aho_grep.c recompile against include/compat/ unchanged.
+ *               Each declaration cites the reference interface it replaces.
+ *
+ * Handle mapping for layer (2):  cl_mem = HIP device pointer,
+ * cl_command_queue = hipStream_t, cl_context = opaque per-device context,
+ * cl_device_id / cl_platform_id = HIP device ordinal + 1 cast to a pointer.
+ */
+#ifndef ACMATCH_H_
+#define ACMATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ====================================================================== */
+/* (1) native boundary                                                    */
+/* ====================================================================== */
+
+enum {
+	ACM_OK = 0,
+	ACM_ERR_ARG = -1,	/* bad argument / misuse                       */
+	ACM_ERR_NOMEM = -2,	/* host or device allocation failed            */
+	ACM_ERR_HIP = -3,	/* a HIP runtime call failed                   */
+	ACM_ERR_NODEV = -4,	/* no usable gfx950 device                     */
+	ACM_ERR_LIMIT = -5,	/* automaton / buffer exceeds a design limit   */
+	ACM_ERR_IO = -6,	/* pattern file could not be opened            */
+	ACM_ERR_PARSE = -7,	/* malformed pattern line                      */
+	ACM_ERR_CAPACITY = -8	/* result planes too small for the matches     */
+};
+
+/* text of the last error raised on the calling thread ("" if none) */
+const char *acm_last_error(void);
+const char *acm_strerror(int code);
+/* library version / build string, e.g. "acmatch 0.1 gfx950" */
+const char *acm_version(void);
+/* number of visible HIP devices (0 when there is none, never an error) */
+int acm_device_count(void);
+
+/* ---------------------------------------------------------------------- */
+/* host-side automaton: pattern list -> acsmx-compatible DFA               */
+/* replaces acsm_new/add_pattern/compile/gen_state_table (acsmx.h:96-141)  */
+/* ---------------------------------------------------------------------- */
+typedef struct acm_automaton acm_automaton;
+
+acm_automaton *acm_automaton_new(void);
+void acm_automaton_free(acm_automaton *);
+
+/* append one pattern; its index is the number of patterns added before it
+ * (acsmx.c:535).  n may be 0 (an empty pattern never reports). */
+int acm_automaton_add(acm_automaton *, const unsigned char *bytes, int n,
+    int iid);
+
+/* pattern-file parser of ocl_worker.c:74-145: one pattern per line, optional
+ * "ID pattern" categorical form decided on the first line, one pair of
+ * surrounding double quotes stripped, hex => printable hex (utils.c:32-54),
+ * max_len = -m limit in bytes or -1.  Returns patterns added or an error. */
+int acm_automaton_load_file(acm_automaton *, const char *path, int hex,
+    int max_len);
+
+/* trie -> fail links -> full DFA, reference state numbering preserved
+ * (acsmx.c:552-594) and a BFS renumbering derived for the device. */
+int acm_automaton_compile(acm_automaton *);
+
+int acm_automaton_num_patterns(const acm_automaton *);
+int acm_automaton_max_pattern_len(const acm_automaton *);
+/* states as acsm_get_states reports them after acsm_gen_state_table */
+int acm_automaton_num_states(const acm_automaton *);
+/* bytes of the reference's serialised table: states * 2 * 256 * 4 */
+size_t acm_automaton_reference_table_bytes(const acm_automaton *);
+/* write the reference-format table [states][2][256] int32 (acsmx.c:640-658);
+ * cells the reference leaves uninitialised are written as 0 */
+int acm_automaton_export_reference_table(const acm_automaton *, int32_t *dst);
+/* pattern i: iid, length, bytes (borrowed pointer), index of the next
+ * pattern chained to it by acsm_get_patterns_table (acsmx.c:707-721) or -1 */
+int acm_automaton_pattern(const acm_automaton *, int index, int *iid, int *n,
+    const unsigned char **bytes, int *next_chained);
+/* head-of-match-list pattern index of reference state s, or -1 */
+int acm_automaton_state_output(const acm_automaton *, int ref_state);
+
+/* ---------------------------------------------------------------------- */
+/* device-resident DFA                                                     */
+/* replaces the d_trans upload of acsm_gen_state_table (acsmx.c:618-666)   */
+/* ---------------------------------------------------------------------- */
+typedef struct acm_dfa acm_dfa;
+
+/* builds the HBM/LDS layout and uploads it to HIP device 'device' */
+int acm_dfa_upload(const acm_automaton *, int device, acm_dfa **out);
+void acm_dfa_release(acm_dfa *);
+size_t acm_dfa_device_bytes(const acm_dfa *);
+int acm_dfa_hot_rows(const acm_dfa *);	/* rows staged in LDS by the scan */
+int acm_dfa_device(const acm_dfa *);
+
+/* ---------------------------------------------------------------------- */
+/* scan pipeline on caller-owned device memory                             */
+/* replaces ocl_aho_match + ocl_prefix_sum + ocl_compact_array             */
+/* (ocl_aho_match.h:28-29, ocl_prefix_sum.h:21-22, ocl_compact_array.h:21) */
+/* ---------------------------------------------------------------------- */
+
+/* bytes of scratch the pipeline needs to scan up to max_text bytes */
+size_t acm_scan_workspace_bytes(const acm_dfa *, size_t max_text);
+
+/*
+ * Scan d_text[0..n) as one byte stream starting from reference state
+ * init_state and produce, in position order, one record per text position
+ * whose transition enters a final state:
+ *
+ *   d_pat_plane[0] = m            d_off_plane[0] = m
+ *   d_pat_plane[1..m] = pattern index (head of match list, acsmx.c:650)
+ *   d_off_plane[1..m] = offset of the LAST byte of the match
+ *   d_*_plane[m+1] = state after the last byte, reference numbering
+ *
+ * i.e. the compact layout of compactarray.cl:49-55 / databuf.c:656-682.
+ * plane_capacity counts int32 cells per plane and must be >= 2; when
+ * m + 2 > plane_capacity the first plane_capacity-2 records are stored,
+ * cell [0] still holds the full m, the state goes to cell
+ * [plane_capacity-1], and ACM_ERR_CAPACITY is reported by acm_scan_finish.
+ *
+ * d_text must be 16-byte aligned and readable up to n rounded up to 16.
+ * Everything is enqueued on 'stream' (a hipStream_t, NULL = default stream);
+ * nothing is synchronised.  n <= 2^31 - 17.
+ */
+int acm_scan_async(const acm_dfa *, const void *d_text, size_t n,
+    long init_state, void *d_workspace, size_t workspace_bytes,
+    int32_t *d_pat_plane, int32_t *d_off_plane, size_t plane_capacity,
+    void *stream);
+
+/* tuning knobs for acm_scan_async; 0 = automatic.  chain_bytes: bytes each
+ * lane walks per tile (power of two, 16..256).  Returns the value in use. */
+int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
+
+/* number of kernels one acm_scan_async enqueues for a non-empty text */
+int acm_scan_kernel_count(void);
+
+/* in-line timing with HIP events on the launch stream: when enabled, every
+ * acm_scan_async records an event before the walk kernel, after it, and after
+ * the last kernel.  acm_scan_profile_read waits for the recorded events,
+ * returns the summed milliseconds of the walk kernel and of the whole
+ * pipeline over 'launches' calls, and resets the accumulation. */
+int acm_scan_profile_enable(acm_dfa *, int enable);
+int acm_scan_profile_read(acm_dfa *, double *walk_ms, double *pipeline_ms,
+    int *launches);
+
+/* ---------------------------------------------------------------------- */
+/* standalone result post-processing ops (device pointers, async)          */
+/* ---------------------------------------------------------------------- */
+
+/* exclusive int32 prefix sum (work-efficient Blelloch up/down sweep in LDS,
+ * recursive over block sums).  Replaces ocl_prefix_sum.c:164-221 +
+ * scan_kernel.cl.  d_in may equal d_out.  d_total (optional) gets the sum. */
+size_t acm_exclusive_scan_workspace_bytes(size_t n);
+int acm_exclusive_scan_i32(const int32_t *d_in, int32_t *d_out, size_t n,
+    int32_t *d_total, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* bucket planes -> dense array; compactarray.cl:40-68 cell for cell:
+ * dst[0]=total, dst[1..]=cells, dst[total+1]=src[max_results*len] */
+int acm_compact_buckets(int32_t *d_dst, const int32_t *d_src,
+    const int32_t *d_prefix, int len, int max_results, void *stream);
+
+/* key/value bitonic sort on uint32 keys, same network as BitonicSort.cl
+ * (tie order included); len must be a power of two; returns 0, or -1 for an
+ * unsupported length like ocl_bitonic_sort.c:154-165.  src may equal dst. */
+int acm_bitonic_sort_u32(uint32_t *d_key_dst, uint32_t *d_val_dst,
+    const uint32_t *d_key_src, const uint32_t *d_val_src, unsigned batch,
+    unsigned len, unsigned dir, void *stream);
+
+/* compact planes (position ordered) -> the reference's bucket planes
+ * results/results2 [max_results][chunks] + trailer (ahomatch.cl:63-75,
+ * :90-93, :160-162 layout; databuf.c:747-782 reads it) */
+int acm_bucketize(const int32_t *d_pat_plane, const int32_t *d_off_plane,
+    const int32_t *d_indices, const int32_t *d_sizes, int chunks,
+    int max_results, int32_t *d_results, int32_t *d_results2, void *stream);
+
+/* chunk list -> contiguous stream and back.  The reference scans chunk by
+ * chunk (indices[]/sizes[], databuf.c:326-481) and chunks may be separated by
+ * zero padding; acm_pack_chunks copies chunk i to d_dst + d_packed_start[i],
+ * acm_remap_offsets rewrites the offsets of a compact plane (scanned over the
+ * packed stream) into offsets of the original buffer.  max_records bounds
+ * the launch; the record count is read from d_off_plane[0] on the device. */
+int acm_pack_chunks(void *d_dst, const void *d_src, const int32_t *d_indices,
+    const int32_t *d_sizes, const int32_t *d_packed_start, int chunks,
+    void *stream);
+int acm_remap_offsets(int32_t *d_off_plane, size_t max_records,
+    const int32_t *d_indices, const int32_t *d_packed_start, int chunks,
+    void *stream);
+
+/* ---------------------------------------------------------------------- */
+/* device-runtime helpers for FFI hosts without a HIP binding              */
+/* ---------------------------------------------------------------------- */
+int acm_rt_set_device(int device);
+int acm_rt_malloc(void **out, size_t bytes);
+int acm_rt_free(void *p);
+int acm_rt_host_alloc(void **out, size_t bytes);	/* pinned */
+int acm_rt_host_free(void *p);
+int acm_rt_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int acm_rt_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int acm_rt_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int acm_rt_memset(void *dst, int value, size_t bytes, void *stream);
+int acm_rt_stream_create(void **out);
+int acm_rt_stream_destroy(void *stream);
+int acm_rt_stream_sync(void *stream);
+int acm_rt_device_sync(void);
+int acm_rt_event_create(void **out);
+int acm_rt_event_destroy(void *ev);
+int acm_rt_event_record(void *ev, void *stream);
+int acm_rt_event_sync(void *ev);
+int acm_rt_event_elapsed_ms(void *start, void *stop, float *ms);
+int acm_rt_device_info(int device, char *name, int name_cap, int *cus,
+    size_t *mem_bytes, int *lds_per_cu);
+
+/* ====================================================================== */
+/* (2) the reference's interface                                           */
+/* ====================================================================== */
+
+/* OpenCL handle names, declared exactly as <CL/cl.h> does so that a caller
+ * that also includes the Khronos headers sees compatible typedefs. */
+#ifndef __OPENCL_CL_H
+typedef struct _cl_platform_id *cl_platform_id;
+typedef struct _cl_device_id *cl_device_id;
+typedef struct _cl_context *cl_context;
+typedef struct _cl_command_queue *cl_command_queue;
+typedef struct _cl_mem *cl_mem;
+typedef struct _cl_program *cl_program;
+typedef struct _cl_kernel *cl_kernel;
+typedef uint64_t cl_device_type;
+#endif
+
+/* ---- ocl_context.h:8-38 ------------------------------------------------ */
+struct clconf {
+	cl_platform_id platform;
+	cl_device_id dev;
+	cl_context ctx;		/* per-device context of this library      */
+	cl_command_queue queue;	/* a hipStream_t                           */
+
+	cl_program program_aho_match;	/* unused: code objects are embedded */
+	cl_kernel kernel_aho_match;
+	cl_program program_prefixsum;
+	cl_kernel kernel_prescan;
+	cl_kernel kernel_prescan_store_sum;
+	cl_kernel kernel_prescan_store_sum_non_power_of_two;
+	cl_kernel kernel_prescan_non_power_of_two;
+	cl_kernel kernel_uniform_add;
+	cl_program program_compact_array;
+	cl_kernel kernel_compact_array;
+
+	cl_device_type type;
+};
+
+/* pick the pos-th device, create context + in-order queue
+ * (ocl_context.c:18-85; subpos is ignored there too) */
+void clinitctx(struct clconf *, int pos, int subpos);
+
+/* ---- acsmx.h:44-196 ---------------------------------------------------- */
+#define ALPHABET_SIZE 256
+#define ACSM_FAIL_STATE -1
+
+struct _acsm_pattern {
+	struct _acsm_pattern *next;
+	unsigned char *pattern;
+	unsigned char *casepattern;
+	int n;
+	int nocase;
+	int offset;
+	int depth;
+	void *id;
+	int iid;
+	unsigned int index;
+};
+typedef struct _acsm_pattern acsm_pattern_t;
+
+struct _acsm_state_table {	/* kept for source compatibility; unused */
+	int next_state[ALPHABET_SIZE];
+	int fail_state;
+	int num_finals;
+	acsm_pattern_t *match_list;
+};
+typedef struct _acsm_state_table acsm_state_table_t;
+
+struct _acsm {
+	int max_states;
+	int num_states;
+	int max_pattern_len;
+	size_t size;
+	acsm_pattern_t *patterns;	/* always NULL here: see 'native'   */
+	int num_patterns;
+	acsm_state_table_t *state_table;	/* always NULL              */
+	int *h_trans;			/* NULL: no host copy is kept       */
+	cl_mem d_trans;			/* device table (cold plane)        */
+	acm_automaton *native;		/* host automaton                   */
+	acm_dfa *dfa;			/* device DFA after gen_state_table */
+};
+typedef struct _acsm acsm_t;
+
+acsm_t *acsm_new(void);						/* acsmx.h:101 */
+void acsm_add_pattern(acsm_t *, unsigned char *, int n, int nocase,
+    int offset, int depth, void *id, int iid);			/* :118 */
+void acsm_compile(acsm_t *);					/* :127 */
+void acsm_gen_state_table(acsm_t *, int mapped, cl_context,
+    cl_command_queue);						/* :139 */
+acsm_pattern_t *acsm_get_patterns_table(acsm_t *);		/* :152 */
+int acsm_get_max_pattern_size(acsm_t *);			/* :162 */
+int acsm_get_states(acsm_t *);					/* :172 */
+size_t acsm_get_size(acsm_t *);					/* :182 */
+void acsm_cleanup(acsm_t *);					/* :191 */
+void acsm_free(acsm_t *);					/* :200 */
+
+/* ---- databuf.h:9-174 --------------------------------------------------- */
+#define MAX_RESULTS 16
+
+struct databuf {
+	unsigned char *h_data;
+	int *h_indices;
+	int *h_sizes;
+	int *h_results;
+	int *h_results2;
+	int *h_prefixsum;
+	int *h_results_comp;
+	int *h_results2_comp;
+
+	size_t results_comp_size;
+	size_t results2_comp_size;
+
+	int *file_ids;
+	int mapped;
+	int max_results;
+	long last_state;
+	size_t max_chunks;
+	size_t max_chunk_size;
+	size_t size;
+	size_t chunks;
+	size_t bytes;
+
+	cl_mem d_data;
+	cl_mem d_indices;
+	cl_mem d_sizes;
+	cl_mem d_results;
+	cl_mem d_results2;
+	cl_mem d_prefixsum;
+	cl_mem d_results_comp;
+	cl_mem d_results2_comp;
+
+	cl_mem p_data;		/* pinned twins: the h_* arrays ARE pinned, */
+	cl_mem p_indices;	/* these stay NULL                          */
+	cl_mem p_sizes;
+	cl_mem p_results;
+	cl_mem p_results2;
+	cl_mem p_prefixsum;
+	cl_mem p_results_comp;
+	cl_mem p_results2_comp;
+
+	cl_mem *ScanPartialSums;	/* unused: scan scratch is in 'ws'  */
+	unsigned int ScanPartialSums_size;
+
+	struct clconf *cl;
+
+	/* additions of this library */
+	void *ws;		/* device scratch of the scan pipeline      */
+	size_t ws_bytes;
+	int compact;		/* 1: process_results reads the compact
+				 * planes (the reference's COMPACT_RESULTS
+				 * build, databuf.c:16); 0: bucket planes   */
+	int scanned;		/* planes on the device are current         */
+};
+
+struct databuf *databuf_new(size_t max_chunks, size_t max_chunk_size,
+    int max_results, int mapped, struct clconf *);	/* databuf.h:79 */
+int databuf_add_fd(struct databuf *, int fd, int id, size_t *rd_bytes);
+int databuf_add_fp(struct databuf *, FILE *, int id, int aligned,
+    size_t *rd_bytes, size_t *rd_lines);
+int databuf_add_chunk(struct databuf *, char *chunk, size_t len, int id,
+    char aligned);					/* databuf.c:487 */
+void databuf_reset(struct databuf *);
+void databuf_clear(struct databuf *);
+void databuf_copy_host_to_device(struct databuf *, cl_command_queue);
+void databuf_copy_device_to_host(struct databuf *, cl_command_queue);
+int databuf_process_results(struct databuf *,
+    int (*cb)(int file_idx, int patrn_idx, int chunk_idx, int offset,
+    void *uarg), void *uarg);
+void databuf_free(struct databuf *, int mapped, cl_command_queue);
+
+/* ---- ocl_aho_match.h:12-30 --------------------------------------------- */
+void ocl_aho_match_init(struct clconf *);
+void ocl_aho_match_close(struct clconf *);
+/* scans db (device copy) and fills the bucket planes AND the compact
+ * planes; blocks until done like the reference's clFinish
+ * (ocl_aho_match.c:125-130).  'stream' is accepted and ignored (:83-90). */
+void ocl_aho_match(struct clconf *, struct databuf *, acsm_t *,
+    size_t local_ws, int stream);
+
+/* ---- ocl_prefix_sum.h:12-22, ocl_compact_array.h:12-22 ----------------- */
+void ocl_prefix_sum_init(struct clconf *);
+void ocl_prefix_sum_close(struct clconf *);
+void ocl_prefix_sum(struct clconf *, struct databuf *, unsigned int n);
+void ocl_compact_array_init(struct clconf *);
+void ocl_compact_array_close(struct clconf *);
+void ocl_compact_array(struct clconf *, struct databuf *, size_t local_ws);
+
+/* ---- ocl_bitonic_sort.h:13-18 ------------------------------------------ */
+int ocl_bitonic_sort_init(struct clconf *);
+int ocl_bitonic_sort_close(struct clconf *);
+int ocl_bitonic_sort(struct clconf *, cl_mem key_dst, cl_mem val_dst,
+    cl_mem key_src, cl_mem val_src, unsigned int batch, unsigned int len,
+    unsigned int dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACMATCH_H_ */

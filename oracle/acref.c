@@ -313,7 +313,7 @@ orc_pattern_info(const orc_t *o, int index, int *iid, int *n,
 void
 orc_patterns_chain(const orc_t *o, int *next_chain)
 {
-	int i, m, q;
+	int i, m, q, hops;
 	for (i = 0; i < o->npats; i++)
 		next_chain[i] = -1;
 	for (i = 0; i < o->max_states; i++) {
@@ -321,13 +321,13 @@ orc_patterns_chain(const orc_t *o, int *next_chain)
 		if (m == -1 || o->mnodes[m].next == -1)
 			continue;
 		q = o->mnodes[m].pat;
-		while (next_chain[q] != -1)
+		/* the reference walks "while (q->next)" unbounded and never
+		 * returns once two states have linked a cycle (it hangs on
+		 * its own apps/patterns.txt); bound the walk instead */
+		for (hops = 0; next_chain[q] != -1 && hops < o->npats; hops++)
 			q = next_chain[q];
 		while (m != -1 && o->mnodes[m].next != -1) {
 			int nx = o->mnodes[o->mnodes[m].next].pat;
-			/* the reference would build a cycle here when a
-			 * pattern is linked to itself; it never happens with
-			 * distinct patterns, stop instead of looping */
 			if (nx == q)
 				break;
 			next_chain[q] = nx;
