@@ -282,7 +282,7 @@ struct Builder {
 		a.bfs_order.clear();
 		a.bfs_order.reserve(n);
 		a.bfs_order.push_back(0);
-		set_list(0, 0);
+		set_list(0, 0, false);
 		for (size_t qh = 0; qh < a.bfs_order.size(); qh++) {
 			uint32_t s = a.bfs_order[qh];
 			for (uint32_t e = a.child_begin[s]; e < a.child_begin[s + 1]; e++) {
@@ -303,15 +303,18 @@ struct Builder {
 					}
 				}
 				a.fail[t] = f;
-				set_list(t, f);
+				// depth-1 states get fail = root WITHOUT inheriting the
+				// root's list (acsmx.c:376-382 vs :417-429); it only
+				// matters when an empty pattern made the root "final"
+				set_list(t, f, /*inherit=*/s != 0);
 				a.bfs_order.push_back(t);
 			}
 		}
 	}
 
-	void set_list(uint32_t s, uint32_t f)
+	void set_list(uint32_t s, uint32_t f, bool inherit)
 	{
-		int inherited = (s == 0) ? 0 : a.list_len[f];
+		int inherited = inherit ? a.list_len[f] : 0;
 		int total = inherited + (int)own[s].size();
 		if (total == 0)
 			return;

@@ -1,0 +1,7 @@
+/* Drop-in replacement for the reference's ocl_compact_array.h: everything is declared in
+ * acmatch.h (layer 2).  Put include/compat first on the include path when
+ * recompiling ocl_worker.c / ocl_aho_grep.c against libacmatch.so. */
+#ifndef ACM_COMPAT_OCL_COMPACT_ARRAY_H_
+#define ACM_COMPAT_OCL_COMPACT_ARRAY_H_
+#include "../acmatch.h"
+#endif

@@ -1,0 +1,195 @@
+"""Parity of the HIP scan pipeline (through the C ABI) with the oracle and the golden
+vectors produced by the reference's acsmx.c.  Bit-exact: offsets, pattern indices, order,
+count and final state (reference numbering).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+import orc
+from gpu_pattern_matching_amd import AcmError, Automaton, DeviceArray, Matcher
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")) as _f:
+    GOLDEN = json.load(_f)["sets"]
+
+_matchers = {}
+
+
+def matcher_for(name, max_text=1 << 20):
+    if name not in _matchers:
+        if len(_matchers) >= 2:       # keep device memory bounded (15000 sigs = 0.7 GB)
+            _matchers.pop(next(iter(_matchers))).close()
+        path, hx, max_len = fixtures.set_source(name)
+        a = Automaton()
+        a.load_file(path, hx, max_len)
+        a.compile()
+        _matchers[name] = Matcher(a, 0, max_text=max_text)
+        a.close()
+    m = _matchers[name]
+    m.reserve(max_text)
+    m.set_chain_bytes(0)
+    return m
+
+
+def assert_same(got, exp):
+    assert got[0].size == exp[0].size, "record count %d != %d" % (got[0].size, exp[0].size)
+    assert np.array_equal(got[0], exp[0]), "offsets differ"
+    assert np.array_equal(got[1], exp[1]), "pattern indices differ"
+    assert got[2] == exp[2], "final state %d != %d" % (got[2], exp[2])
+
+
+GOLDEN_CASES = [(name, i) for name in GOLDEN for i in range(len(GOLDEN[name]["texts"]))]
+
+
+@pytest.mark.parametrize("name,idx", GOLDEN_CASES,
+                         ids=["%s-%s" % (n, fixtures.spec_id(GOLDEN[n]["texts"][i])) for n, i in GOLDEN_CASES])
+def test_golden_vectors(gpu, name, idx):
+    """Every golden vector, at BASELINE's full 32 MiB sizes too, by digest (no oracle needed)."""
+    spec = GOLDEN[name]["texts"][idx]
+    pats = fixtures.patterns_of(name) if spec["kind"] in ("clamav", "repeat") else None
+    text = fixtures.text_for(spec, pats)
+    assert hashlib.sha256(text.tobytes()).hexdigest() == spec["sha256"]
+    m = matcher_for(name, max_text=max(text.size, 1 << 20))
+    pos, pat, last = m.scan(text)
+    assert pos.size == spec["count"]
+    assert "%016x" % orc.records_digest(pos, pat) == spec["records_digest"]
+    assert last == spec["final_state"]
+    assert [[int(a), int(b)] for a, b in zip(pos[:8], pat[:8])] == spec["first_records"]
+    assert (np.diff(pos.astype(np.int64)) > 0).all()      # strictly increasing offsets
+
+
+@pytest.mark.parametrize("chain", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("name", ["tests", "sentiment", "clamav2000", "clamav2000_m12"])
+def test_chain_length_invariance(gpu, name, chain):
+    """The result must not depend on how the text is cut into chains."""
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    if name == "sentiment":
+        text = fixtures.text_for({"kind": "words", "n": 300001, "seed": 4}, None)
+    else:
+        text = fixtures.text_for({"kind": "clamav", "n": 300001, "seed": 4, "n_plant": 300}, pats)
+    m = matcher_for(name)
+    m.set_chain_bytes(chain)
+    assert_same(m.scan(text), o.scan(text))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 4095, 4096, 4097, 8191,
+                               65535, 65537])
+def test_ragged_lengths(gpu, n):
+    o = fixtures.oracle_for("tests")
+    base = np.fromfile(os.path.join(orc.DATA, "ref_tests", "input.txt"), dtype=np.uint8)
+    text = np.tile(base, 8)[:n]
+    m = matcher_for("tests")
+    for chain in (16, 64):
+        m.set_chain_bytes(chain)
+        assert_same(m.scan(text), o.scan(text))
+
+
+def test_streaming_last_state_contract(gpu):
+    """databuf.c:622 / ahomatch.cl:42-43: the state after one buffer seeds the next; cutting a
+    text anywhere (also inside a match) and carrying last_state gives the one-shot answer."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    text = fixtures.text_for({"kind": "clamav", "n": 1 << 18, "seed": 12, "n_plant": 400}, pats)
+    whole = o.scan(text)
+    m = matcher_for(name)
+    rng = np.random.default_rng(12)
+    cuts = sorted(set(int(c) for c in rng.integers(1, text.size - 1, size=5)) |
+                  {int(whole[0][3]) - 2, int(whole[0][10])})   # two cuts inside matches
+    pos_all, pat_all, state, start = [], [], 0, 0
+    for cut in cuts + [text.size]:
+        pos, pat, state = m.scan(text[start:cut], state)
+        pos_all.append(pos.astype(np.int64) + start)
+        pat_all.append(pat)
+        start = cut
+    assert np.array_equal(np.concatenate(pos_all), whole[0].astype(np.int64))
+    assert np.array_equal(np.concatenate(pat_all), whole[1])
+    assert state == whole[2]
+
+
+def test_deep_states_everywhere(gpu):
+    """Worst case for the boundary resolve: every chain starts deep inside a pattern."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    m = matcher_for(name)
+    longest = max(range(len(pats)), key=lambda i: len(pats[i]))
+    for pid in (5, longest):
+        p = pats[pid]
+        text = np.frombuffer((p * (200000 // len(p) + 1))[:200000], dtype=np.uint8)
+        for chain in (16, 64, 256):
+            m.set_chain_bytes(chain)
+            assert_same(m.scan(text), o.scan(text))
+
+
+def test_every_position_matches(gpu):
+    """Maximum result density: a one-byte pattern over a constant text (m == n)."""
+    a = Automaton()
+    a.add(b"a", 7)
+    a.add(b"aa", 8)
+    a.compile()
+    o = orc.Oracle()
+    o.add(b"a", 7)
+    o.add(b"aa", 8)
+    o.compile()
+    text = np.full(100000, ord("a"), dtype=np.uint8)
+    m = Matcher(a, 0, max_text=text.size)
+    for chain in (16, 256):
+        m.set_chain_bytes(chain)
+        got = m.scan(text)
+        assert got[0].size == text.size
+        assert_same(got, o.scan(text))
+    m.close()
+
+
+def test_idempotent_and_async_reuse(gpu):
+    """Scanning the same resident buffer repeatedly (the bench loop) never changes the answer."""
+    name = "sentiment"
+    o = fixtures.oracle_for(name)
+    text = fixtures.text_for({"kind": "words", "n": 1 << 19, "seed": 2}, None)
+    exp = o.scan(text)
+    m = matcher_for(name)
+    d = DeviceArray.from_numpy(text)
+    for _ in range(5):
+        m.scan_async(d, text.size)
+    assert_same(m.fetch(), exp)
+    d.free()
+
+
+def test_capacity_overflow_is_reported(gpu):
+    name = "sentiment"
+    text = fixtures.text_for({"kind": "words", "n": 1 << 16, "seed": 2}, None)
+    exp = fixtures.oracle_for(name).scan(text)
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=text.size, plane_capacity=100)
+    d = DeviceArray.from_numpy(text)
+    m.scan_async(d, text.size)
+    with pytest.raises(AcmError) as e:
+        m.fetch()
+    assert e.value.code == -8
+    pat = m.pat_plane.to_numpy(np.int32, 100)
+    off = m.off_plane.to_numpy(np.int32, 100)
+    assert pat[0] == exp[0].size                       # full count still reported
+    assert np.array_equal(off[1:99], exp[0][:98].astype(np.int32))   # first capacity-2 records
+    assert pat[99] == exp[2]                           # state in the last cell
+    m.close()
+
+
+def test_bad_arguments(gpu, lib):
+    m = matcher_for("tests")
+    d = DeviceArray(64)
+    with pytest.raises(AcmError):
+        m.scan_async(d, 16, init_state=10 ** 6)        # not a state
+    with pytest.raises(AcmError):
+        m.scan_async(d.ptr + 1, 16)                    # misaligned text
+    d.free()
