@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): input GB/s scanned (+ matches/s), 32 MB text x N ClamAV signatures.
+A step = one pass of the scan pipeline (walk -> resolve -> prefix sum -> scatter) over one
+32 MiB batch already resident in HBM; with N > 1 GPUs the logical text is N x 32 MiB, rank g
+scans shard g (+ an (L-1)-byte halo), the DFA is replicated and every step ends with the RCCL
+gather of the compact match planes to rank 0 (double-buffered, overlapped with the next
+step's scan).  Weak scaling: 32 MiB per GPU.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SHARD = 32 << 20
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sigs", type=int, default=2000, choices=[2000, 10000, 15000])
+    ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
+    ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
+    ap.add_argument("--plant", type=int, default=4096)
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import synth  # tests/synth.py: seeded corpus
+    from gpu_pattern_matching_amd import Automaton, Matcher, build, sharding
+    build.build()          # no-op when libacmatch.so is current; raises if it cannot be built
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- automaton: first --sigs ClamAV signatures (clamav_sample_sigs/<N>.txt are prefixes) ----
+    sig_path = os.path.join(ROOT, "tests", "data", "clamav", "15000.txt")
+    pats = synth.load_hex_patterns(sig_path, args.sigs, args.max_len)
+    t0 = time.perf_counter()
+    aut = Automaton()
+    for i, p in enumerate(pats):
+        aut.add(p, i)
+    aut.compile()
+    t_compile = time.perf_counter() - t0
+    L = aut.max_pattern_len
+    states = aut.num_states
+    matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
+    matcher.set_chain_bytes(args.chain)
+    aut.close()
+    log(rank, "automaton: %d sigs, %d states, L=%d, compile %.2fs, device %.1f MB, hot rows %d" % (
+        len(pats), states, L, t_compile, matcher.device_bytes / 1e6, matcher.hot_rows))
+
+    # ---- text: logical text = world shards of 32 MiB; shard r = seeded corpus(seed 7 + r) ------
+    def shard_text(r):
+        return synth.clamav_corpus(SHARD, 7 + r, pats, args.plant)
+
+    total_bytes = SHARD * world
+    plan = sharding.shard_plan(total_bytes, world, rank, L)
+    mine = shard_text(rank)
+    if plan["halo"]:
+        mine = np.concatenate([shard_text(rank - 1)[-plan["halo"]:], mine])
+    n_local = mine.size
+    assert n_local == plan["load_bytes"]
+    d_text = torch.zeros((n_local + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+    d_text[:n_local] = torch.from_numpy(mine).to(dev)
+    ws_bytes = matcher.lib.acm_scan_workspace_bytes(matcher.dfa, n_local)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    cap = 1 << 16                                   # cells per plane; 3.8k records expected
+    planes = [torch.zeros((2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    pending = [None, None]
+
+    def step(k):
+        buf = k & 1
+        if pending[buf] is not None:                # the gather that last used this buffer
+            pending[buf].wait()
+            pending[buf] = None
+        p = planes[buf]
+        matcher.scan_async(d_text, n_local, 0, stream, p[0], p[1], cap, halo=plan["halo"],
+                           offset_shift=plan["offset_shift"], workspace=(ws, ws_bytes))
+        if world > 1:
+            bufs = gathered[buf] if rank == 0 else None
+            pending[buf] = dist.gather(p, gather_list=bufs, dst=0, async_op=True)
+
+    gathered = [[torch.empty_like(planes[0]) for _ in range(world)] for _ in range(2)] \
+        if (world > 1 and rank == 0) else [None, None]
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    fence()
+    matcher.profile(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    walk_ms, pipe_ms, launches = matcher.profile_read()
+    matcher.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- results of the last step -------------------------------------------------------------
+    last = (args.steps - 1) & 1 if args.steps > 0 else 0
+    local = planes[last].cpu().numpy()
+    m_local = int(local[0, 0])
+    m_total = m_local
+    if world > 1:
+        t = torch.tensor([m_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        m_total = int(t.item())
+
+    out = None
+    if rank == 0:
+        if world > 1:
+            offs, pids, last_state = sharding.merge_gathered(gathered[last])
+        else:
+            offs, pids, last_state = sharding.merge_gathered([local])
+        assert offs.size == m_total
+
+        parity = "not checked"
+        cpu = None
+        if not args.no_verify or not args.no_cpu_baseline:
+            import orc  # tests/orc.py -> oracle/ (checker + CPU baseline only)
+            o = orc.Oracle()
+            for i, p in enumerate(pats):
+                o.add(p, i)
+            o.compile()
+            whole = mine if world == 1 else np.concatenate([shard_text(r) for r in range(world)])
+            if not args.no_verify:
+                epos, epat, elast = o.scan(whole)
+                ok = (np.array_equal(epos, offs) and np.array_equal(epat, pids) and elast == last_state)
+                parity = "bit-exact vs oracle serial scan (%d records, final state %d)" % (
+                    epos.size, elast) if ok else "MISMATCH"
+                if not ok:
+                    log(rank, "PARITY MISMATCH: gpu %d records / oracle %d" % (offs.size, epos.size))
+            if world == 1 and not args.no_cpu_baseline:
+                best, reps, t_start = 1e30, 0, time.perf_counter()
+                while time.perf_counter() - t_start < args.cpu_seconds or reps < 2:
+                    t1 = time.perf_counter()
+                    o.scan_count(mine)
+                    best = min(best, time.perf_counter() - t1)
+                    reps += 1
+                ncpu = os.cpu_count() or 1
+                t1 = time.perf_counter()
+                o.scan_threads(mine, ncpu)
+                t_all = time.perf_counter() - t1
+                cpu = {"value": round(SHARD / best / 1e9, 4), "unit": "GB/s", "cores": 1,
+                       "kind": "port",
+                       "sample": "oracle/acref.c serial walk of the reference-format int32 table over "
+                                 "the same 32 MiB text, best of %d passes (%.1f s of CPU work)" % (
+                                     reps, time.perf_counter() - t_start),
+                       "all_cores": {"value": round(SHARD / t_all / 1e9, 4), "cores": ncpu}}
+            o.close()
+
+        walk_s = walk_ms / 1e3 / max(launches, 1)
+        alg_bytes = n_local + 8 * m_local
+        achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
+        value = total_bytes * args.steps / elapsed / 1e9
+        traffic = None
+        tpath = os.environ.get("ACM_HBM_TRAFFIC_BYTES")     # per-launch PMC figure, see profiles/
+        if tpath:
+            traffic = float(tpath)
+        out = {
+            "metric": "input_GB_per_s_scanned",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "32 MiB per GPU of seeded uniform bytes + %d planted signatures x first %d "
+                            "ClamAV sigs%s (%d states, max len %d); scan -> resolve -> prefix-sum -> "
+                            "scatter, match planes gathered to rank 0" % (
+                                args.plant, args.sigs,
+                                "" if args.max_len < 0 else " (-m %d)" % args.max_len, states, L),
+                "text_bytes_per_gpu": SHARD,
+                "signatures": args.sigs,
+                "chain_bytes": matcher.set_chain_bytes(args.chain) or "auto",
+                "parallelism": "text sharded %d-way, DFA replicated" % world,
+            },
+            "matches_per_step": m_total,
+            "matches_per_s": round(m_total * args.steps / elapsed, 1),
+            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 5),
+            "parity": parity,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_spec_walk",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_us": round(walk_s * 1e6, 2),
+                "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
+            },
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    matcher.close()
+    if out is not None and out["parity"] == "MISMATCH":
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -173,13 +173,18 @@ class Matcher:
         return self.lib.acm_scan_set_chain_bytes(self.dfa, s)
 
     def scan_async(self, d_text, n, init_state=0, stream=None, pat_plane=None, off_plane=None,
-                   plane_capacity=None):
-        """Enqueue one scan of device text; nothing is synchronised."""
-        if n > self.max_text:
+                   plane_capacity=None, halo=0, offset_shift=0, workspace=None):
+        """Enqueue one scan of device text; nothing is synchronised.
+
+        halo/offset_shift: shard form (acm_scan_shard_async).  workspace: (ptr, nbytes) of a
+        caller-owned scratch block instead of the matcher's own.
+        """
+        if workspace is None and n > self.max_text:
             raise ValueError("text of %d bytes exceeds reserved %d" % (n, self.max_text))
         st = stream if stream is not None else self.stream
-        check(self.lib.acm_scan_async(self.dfa, _ptr(d_text), n, init_state, self.ws.ptr,
-                                      self.ws_bytes,
+        ws_ptr, ws_bytes = workspace if workspace is not None else (self.ws.ptr, self.ws_bytes)
+        check(self.lib.acm_scan_shard_async(self.dfa, _ptr(d_text), n, halo, offset_shift, init_state,
+                                      _ptr(ws_ptr), ws_bytes,
                                       _ptr(pat_plane) if pat_plane is not None else self.pat_plane.ptr,
                                       _ptr(off_plane) if off_plane is not None else self.off_plane.ptr,
                                       plane_capacity if plane_capacity is not None

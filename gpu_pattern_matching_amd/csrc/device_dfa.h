@@ -29,4 +29,5 @@ struct acm_dfa {
 	// {before walk, after walk, after last kernel} per recorded launch
 	mutable bool profile = false;
 	mutable std::vector<void *> profile_events;
+	mutable std::vector<void *> profile_pool;   // idle events, reused
 };

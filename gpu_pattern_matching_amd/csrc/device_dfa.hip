@@ -125,6 +125,10 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_dev2ref);
 		hipFree(d->d_depth_cum);
 		hipFree(d->d_depth_final);
+		for (void *e : d->profile_events)
+			hipEventDestroy((hipEvent_t)e);
+		for (void *e : d->profile_pool)
+			hipEventDestroy((hipEvent_t)e);
 	}
 	delete d;
 }

@@ -37,6 +37,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 
 #include "acm_internal.h"
@@ -67,6 +69,8 @@ struct ScanArgs {
 	uint32_t L;             // max pattern length
 	uint32_t q;             // look-back chains
 	uint32_t init_state;    // dev numbering
+	uint32_t drop_before;   // records ending before this offset are context (halo), not output
+	int32_t off_shift;      // added to every reported offset
 	// workspace
 	uint32_t *end_state;
 	uint32_t *c1f;
@@ -140,6 +144,7 @@ __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot,
 	if (__builtin_amdgcn_ballot_w64(any_hit)) {
 #pragma unroll
 		for (int c = 0; c < C; c++) {
+			hit[c] = hit[c] && (base[c] + step - 1 >= a.drop_before);
 			const uint64_t m = __builtin_amdgcn_ballot_w64(hit[c]);
 			if (m) {
 				if (hit[c]) {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 					merged = true;
 					break;
 				}
-				if (state >= a.F) {
+				if (state >= a.F && base + m - 1 >= a.drop_before) {
 					const uint32_t slot = atomicAdd(&wave_fill[wv], 1u);
 					stage[slot] = make_uint2(base + m - 1, state | (c2 << 24));
 					c2++;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void k_scatter(ScanArgs a, uint32_t regions, u
 		}
 		if (d + 2 < a.plane_capacity) {
 			a.pat_plane[1 + d] = a.out[st];
-			a.off_plane[1 + d] = (int32_t)pos;
+			a.off_plane[1 + d] = (int32_t)pos + a.off_shift;
 		}
 	}
 }
@@ -429,12 +434,23 @@ extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, lo
     void *d_workspace, size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
     size_t plane_capacity, void *stream)
 {
+	return acm_scan_shard_async(d, d_text, n, 0, 0, init_state, d_workspace, workspace_bytes,
+	    d_pat_plane, d_off_plane, plane_capacity, stream);
+}
+
+extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t n, size_t halo,
+    long offset_shift, long init_state, void *d_workspace, size_t workspace_bytes,
+    int32_t *d_pat_plane, int32_t *d_off_plane, size_t plane_capacity, void *stream)
+{
 	if (!d || !d_pat_plane || !d_off_plane || plane_capacity < 2 || (n && !d_text))
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: bad arguments");
 	if (n > 0x7FFFFFEFul)
 		return acm::fail(ACM_ERR_LIMIT, "acm_scan_async: %zu bytes exceed the 2 GiB buffer limit", n);
 	if (((uintptr_t)d_text & 15) != 0)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: text must be 16-byte aligned");
+	if (halo > n || offset_shift < INT32_MIN || offset_shift > INT32_MAX ||
+	    (long)n + offset_shift > (long)INT32_MAX)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_shard_async: halo/offset_shift out of range");
 	if (init_state < 0 || (uint64_t)init_state >= d->num_states)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: init_state %ld is not a state", init_state);
 	if (plane_capacity > 0xFFFFFFFFul)
@@ -483,6 +499,8 @@ extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, lo
 	if (a.q == 0)
 		a.q = 1;
 	a.init_state = d->ref2dev[(size_t)init_state];
+	a.drop_before = (uint32_t)halo;
+	a.off_shift = (int32_t)offset_shift;
 	a.end_state = (uint32_t *)(ws + l.end_state);
 	a.c1f = (uint32_t *)(ws + l.c1f);
 	a.k2info = (uint32_t *)(ws + l.k2info);
@@ -505,8 +523,14 @@ extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, lo
 
 	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 	if (d->profile) {
-		for (auto &e : ev)
-			ACM_HIP_TRY(hipEventCreate(&e));
+		for (auto &e : ev) {
+			if (!d->profile_pool.empty()) {  // recycled: no create/destroy in a timed loop
+				e = (hipEvent_t)d->profile_pool.back();
+				d->profile_pool.pop_back();
+			} else {
+				ACM_HIP_TRY(hipEventCreate(&e));
+			}
+		}
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	}
 	int rc = launch_spec_walk<C>(a, d->num_cus, s);
@@ -558,9 +582,9 @@ extern "C" int acm_scan_profile_read(acm_dfa *d, double *walk_ms, double *pipeli
 		walk += a;
 		pipe += b;
 		n++;
-		hipEventDestroy(e0);
-		hipEventDestroy(e1);
-		hipEventDestroy(e2);
+		d->profile_pool.push_back((void *)e0);
+		d->profile_pool.push_back((void *)e1);
+		d->profile_pool.push_back((void *)e2);
 	}
 	d->profile_events.clear();
 	if (walk_ms) *walk_ms = walk;

@@ -142,6 +142,20 @@ int acm_scan_async(const acm_dfa *, const void *d_text, size_t n,
     int32_t *d_pat_plane, int32_t *d_off_plane, size_t plane_capacity,
     void *stream);
 
+/*
+ * Shard form of acm_scan_async for texts split across devices (or rounds):
+ * the first 'halo' bytes of d_text are context only -- they warm the state
+ * up, records ending inside them are dropped -- and every reported offset is
+ * shifted by offset_shift (e.g. shard_base - halo, to report offsets in the
+ * coordinates of the whole text).  With halo >= max_pattern_len - 1 bytes of
+ * real preceding text and init_state 0, the records equal those of the
+ * serial scan of the whole text restricted to this shard.
+ */
+int acm_scan_shard_async(const acm_dfa *, const void *d_text, size_t n,
+    size_t halo, long offset_shift, long init_state, void *d_workspace,
+    size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
+    size_t plane_capacity, void *stream);
+
 /* tuning knobs for acm_scan_async; 0 = automatic.  chain_bytes: bytes each
  * lane walks per tile (power of two, 16..256).  Returns the value in use. */
 int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
