@@ -70,6 +70,13 @@ struct acm_automaton {
 	uint32_t first_final = 0;              // dev ids >= this are final
 	std::vector<uint32_t> depth_cum;       // [m] non-final states with depth <= m, m = 0..max_len
 	std::vector<int32_t> next_chained;     // [pattern] acsm_get_patterns_table chain
+	// fast-forward along unary trie paths: ref ids are consecutive along the
+	// states one pattern insertion creates (acsmx.c:339-344), so from ref
+	// state r the next ff_run[r] states are r+1, r+2, ... reached on bytes
+	// in_byte[r+1], in_byte[r+2], ... -- each with exactly one child and
+	// none of them final.  Lets the deep walks compare 16 text bytes per
+	// dependent load instead of one table lookup per byte.
+	std::vector<uint8_t> ff_run;           // [ref], capped at 255
 
 	// dense DFA, dev numbering, [num_states][256]; built on first use
 	mutable std::vector<uint32_t> dense;

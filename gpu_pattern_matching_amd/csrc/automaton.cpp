@@ -357,6 +357,25 @@ struct Builder {
 			a.depth_cum[m] += a.depth_cum[m - 1];
 	}
 
+	// ff_run[r]: how many steps r -> r+1 -> ... stay on a path where the
+	// state left has exactly one child (the next ref id) and the state
+	// entered is not final.  Computed right to left.
+	void unary_runs()
+	{
+		const uint32_t n = a.num_states;
+		a.ff_run.assign(n, 0);
+		for (uint32_t r = n; r-- > 0;) {
+			if (r + 1 >= n)
+				continue;
+			const bool one_child = a.child_begin[r + 1] - a.child_begin[r] == 1 &&
+			    a.child_list[a.child_begin[r]].to == r + 1;
+			if (!one_child || a.is_final_ref(r + 1) || r == 0)
+				continue;
+			const uint32_t next = a.ff_run[r + 1];
+			a.ff_run[r] = (uint8_t)(next >= 254 ? 255 : next + 1);
+		}
+	}
+
 	// acsm_get_patterns_table's linking pass (acsmx.c:707-721), state ids
 	// ascending.  The reference's "walk to the end of q's chain" never ends
 	// once two states have linked their patterns into a cycle -- it does so
@@ -406,6 +425,7 @@ extern "C" int acm_automaton_compile(acm_automaton *a)
 		b.link_and_collect();
 		b.number_for_device();
 		b.chain_patterns();
+		b.unary_runs();
 	} catch (const std::bad_alloc &) {
 		return acm::fail(ACM_ERR_NOMEM, "out of memory while compiling the automaton");
 	}

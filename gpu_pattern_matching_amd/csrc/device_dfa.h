@@ -18,6 +18,9 @@ struct acm_dfa {
 	uint32_t *d_dev2ref = nullptr;
 	uint32_t *d_depth_cum = nullptr;
 	uint16_t *d_depth_final = nullptr;
+	uint32_t *d_ffinfo = nullptr;        // [dev] ref id | unary run << 24
+	uint32_t *d_ref2dev = nullptr;       // [ref]
+	uint8_t *d_in_byte = nullptr;        // [ref + 32] byte on the edge into ref state
 	size_t device_bytes = 0;
 
 	std::vector<uint32_t> ref2dev;       // host copies for init_state / last_state

@@ -18,6 +18,10 @@
 //   dev2ref u32 [states]       back to the reference's numbering (last_state)
 //   depth_cum u32 [L+2]        non-final ids < depth_cum[m]  <=>  depth <= m
 //   depth_final u16 [finals]   depth of final state first_final + i
+//   ffinfo u32 [states], ref2dev u32 [states], in_byte u8 [states]:
+//                              fast-forward along unary trie paths for the
+//                              deep walks of the resolve stage (ref ids are
+//                              consecutive along such a path)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -90,7 +94,19 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		for (uint32_t s = a->first_final; s < n; s++)
 			dfin[s - a->first_final] = a->depth[a->dev2ref[s]];
 
+		std::vector<uint32_t> ffinfo(n);
+		for (uint32_t s = 0; s < n; s++) {
+			const uint32_t r = a->dev2ref[s];
+			ffinfo[s] = r | ((uint32_t)a->ff_run[r] << 24);
+		}
+		std::vector<uint8_t> inb(a->in_byte);
+		inb.resize((size_t)n + 32, 0);
+
 		rc = upload(&d->d_cold, rows.data(), rows.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_ffinfo, ffinfo.data(), ffinfo.size(), &d->device_bytes);
+		if (rc == ACM_OK)
+			rc = upload(&d->d_ref2dev, a->ref2dev.data(), a->ref2dev.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_out, outp.data(), outp.size(), &d->device_bytes);
 		if (rc == ACM_OK)
@@ -125,6 +141,9 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_dev2ref);
 		hipFree(d->d_depth_cum);
 		hipFree(d->d_depth_final);
+		hipFree(d->d_ffinfo);
+		hipFree(d->d_ref2dev);
+		hipFree(d->d_in_byte);
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

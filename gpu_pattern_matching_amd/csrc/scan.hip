@@ -58,9 +58,13 @@ struct ScanArgs {
 	const uint32_t *dev2ref;
 	const uint32_t *depth_cum;
 	const uint16_t *depth_final;
+	const uint32_t *ffinfo;
+	const uint32_t *ref2dev;
+	const uint8_t *in_byte;
 	const uint4 *text16;
 	const uint8_t *text;
 	uint32_t n;             // text bytes
+	uint32_t n_pad;         // n rounded up to 16 (readable)
 	uint32_t S, logS;       // chain bytes
 	uint32_t n_chains;
 	uint32_t n_tiles;       // K1 wave tiles
@@ -75,6 +79,8 @@ struct ScanArgs {
 	uint32_t *end_state;
 	uint32_t *c1f;
 	uint32_t *k2info;
+	uint32_t *wend;         // [chains] end state of the probe walk of chain c from e[c-1]
+	uint8_t *probe;         // [chains] bit0: probe merged, bit1: chain needs an emission walk
 	int32_t *cnt;
 	int32_t *off;
 	uint32_t *wave_cnt1;
@@ -234,17 +240,127 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 	}
 }
 
-__device__ __forceinline__ bool depth_le(const ScanArgs &a, uint32_t s, uint32_t m)
+__device__ __forceinline__ bool depth_le(const ScanArgs &a, const uint32_t *cum, uint32_t s,
+    uint32_t m)
 {
 	if (s < a.F)
-		return s < a.depth_cum[min(m, a.L + 1)];
+		return s < cum[min(m, a.L + 1)];
 	return a.depth_final[s - a.F] <= m;
 }
 
-// K2: one lane per chain.
+// depth_cum[] into LDS (dynamic, (L + 2) words) so the merge test costs no
+// global load on the walk's dependent chain
+__device__ __forceinline__ uint32_t *stage_depth_cum(const ScanArgs &a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t cum_lds[];
+	for (uint32_t i = threadIdx.x; i < a.L + 2; i += blockDim.x)
+		cum_lds[i] = a.depth_cum[i];
+	__syncthreads();
+	return cum_lds;
+}
+
+// byte m-1 (m = 1-based step) of the text starting at 16-byte aligned 'base';
+// a 16-byte group is loaded when the walk enters it, off the dependent chain
+struct ChainText {
+	const uint4 *p;
+	uint4 w;
+	uint32_t group;
+	__device__ __forceinline__ ChainText(const ScanArgs &a, uint32_t base)
+	    : p(a.text16 + (base >> 4)), group(0xFFFFFFFFu)
+	{
+		w = make_uint4(0, 0, 0, 0);
+	}
+	__device__ __forceinline__ uint32_t at(uint32_t m)
+	{
+		const uint32_t g = (m - 1) >> 4, k = (m - 1) & 15;
+		if (g != group) {
+			w = p[g];
+			group = g;
+		}
+		const uint32_t d = k < 8 ? (k < 4 ? w.x : w.y) : (k < 12 ? w.z : w.w);
+		return (d >> (8 * (k & 3))) & 0xFFu;
+	}
+};
+
+// Fast-forward along a unary trie path.  'state' (dev id) was just entered;
+// text byte 'pos' is the next one to consume and at most 'limit' bytes may be
+// consumed.  While the text agrees with the single outgoing edge of each
+// state, the walk goes r -> r+1 -> ... in reference numbering, none of the
+// states entered is final, and depth grows in step with the bytes consumed
+// (so an unmerged walk stays unmerged).  Three dependent loads move the walk
+// up to 16 bytes; a table lookup per byte would need 16.
+__device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, uint32_t &state, uint32_t pos,
+    uint32_t limit)
+{
+	if (limit == 0 || pos + 16 > a.n_pad)
+		return 0;
+	const uint32_t info = a.ffinfo[state];
+	uint32_t run = info >> 24;
+	if (run == 0)
+		return 0;
+	const uint32_t r = info & 0xFFFFFFu;
+	run = min(min(run, limit), 16u);
+	uint64_t e0, e1, t0, t1;
+	__builtin_memcpy(&e0, a.in_byte + r + 1, 8);
+	__builtin_memcpy(&e1, a.in_byte + r + 9, 8);
+	__builtin_memcpy(&t0, a.text + pos, 8);
+	__builtin_memcpy(&t1, a.text + pos + 8, 8);
+	const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
+	uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
+			   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
+	same = min(same, run);
+	if (same)
+		state = a.ref2dev[r + same];
+	return same;
+}
+
+// K2a probe: lane c walks chain c from e[c-1] (the state chain c would start
+// in if chain c-1 has merged -- the overwhelmingly common case) until the
+// depth test says it has merged with chain c's own root walk.  It records
+// whether it merged, the state at the end of the chain under that
+// assumption (wend), and whether anything in the unmerged head needs an
+// emission walk (a true hit there, or a K1 hit that must be dropped).
+// All lanes are independent: ~2 dependent loads in the common case.
+__global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
+{
+	const uint32_t *cum = stage_depth_cum(a);
+	const uint32_t c = blockIdx.x * kBlock2 + threadIdx.x;
+	if (c >= a.n_chains)
+		return;
+	uint32_t s = c == 0 ? a.init_state : a.end_state[c - 1];
+	const uint32_t base = c << a.logS;
+	const uint32_t len = min(a.S, a.n - base);
+	const uint32_t f = a.c1f[c] >> 16;
+	bool merged = (s == 0), work = false;
+	if (!merged) {
+		ChainText txt(a, base);
+		for (uint32_t m = 1; m <= len; m++) {
+			s = a.cold[((size_t)s << 8) | txt.at(m)];
+			if (depth_le(a, cum, s, m)) {
+				merged = true;
+				break;
+			}
+			work |= (s >= a.F) | (m >= f);
+			if (s >= a.H && s < a.F) {
+				m += fast_forward(a, s, base + m, len - m);
+				work |= (m >= f);
+			}
+		}
+	}
+	a.wend[c] = merged ? a.end_state[c] : s;
+	a.probe[c] = (uint8_t)((merged ? 1u : 0u) | (work ? 2u : 0u));
+}
+
+// K2b resolve: one lane per chain.  Fast path: every chain of the look-back
+// window merged in its probe, so the true start state is wend[j-1] and, when
+// that equals e[j-1], the probe of chain j IS the true walk of its head.
+// Otherwise the general algorithm runs for this lane: rebuild the start
+// state by walking, then walk the head of the own chain, staging hits.
 __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 {
 	__shared__ uint32_t wave_fill[kBlock2 / 64];
+	__shared__ uint32_t wave_sum[kBlock2 / 64];
+	const uint32_t *cum = stage_depth_cum(a);
 	const uint32_t j = blockIdx.x * kBlock2 + threadIdx.x;
 	const uint32_t wv = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 0)
@@ -252,93 +368,221 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 	__syncthreads();
 	const uint32_t gw = j >> 6;
 	uint2 *stage = a.stage2 + (((size_t)gw * 64) << a.logS);
+	uint32_t my_cnt = 0;
 
 	if (j < a.n_chains) {
-		// ---- true state at the start of chain j -------------------------
-		uint32_t state, c;
-		if (j < a.q) {
-			state = a.init_state;
-			c = 0;
-		} else {
-			state = a.end_state[j - a.q];
-			c = j - a.q + 1;
-		}
-		uint32_t m = 0;
-		while (c < j) {
-			if (m == 0 && state == 0) {  // root: already merged with chain c's own walk
-				state = a.end_state[c];
-				c++;
-				continue;
-			}
-			m++;
-			state = a.cold[((size_t)state << 8) | a.text[((size_t)c << a.logS) + m - 1]];
-			if (depth_le(a, state, m)) {
-				state = a.end_state[c];
-				c++;
-				m = 0;
-			} else if (m == a.S) {
-				c++;
-				m = 0;
-			}
-		}
-		// ---- head of the own chain ---------------------------------------
-		const uint32_t base = j << a.logS;
-		const uint32_t len = min(a.S, a.n - base);
 		const uint32_t info = a.c1f[j];
 		const uint32_t c1 = info & 0xFFFFu, f = info >> 16;
-		uint32_t c2 = 0;
-		bool killed = false, merged = (state == 0);
-		if (!merged) {
-			for (m = 1; m <= len; m++) {
-				state = a.cold[((size_t)state << 8) | a.text[(size_t)base + m - 1]];
-				if (!killed && depth_le(a, state, m)) {
-					merged = true;
-					break;
+		const uint32_t first = j < a.q ? 0u : j - a.q + 1;   // first chain the look-back walks
+		// ---- fast path -----------------------------------------------------
+		bool window_ok = true;
+		for (uint32_t c = first; c + 1 < j; c++)            // chains first .. j-2 must have merged
+			window_ok &= (a.probe[c] & 1u) != 0;
+		const uint32_t pj = a.probe[j];
+		const uint32_t assumed = j == 0 ? a.init_state : a.end_state[j - 1];
+		// q == 1 (S >= L): the window is empty and e[j-1] is already the true state
+		uint32_t state = (j == 0 || first == j) ? assumed : a.wend[j - 1];
+		if (window_ok && state == assumed && !(pj & 2u)) {
+			a.k2info[j] = 0;
+			my_cnt = c1;
+			if (j == a.n_chains - 1)
+				a.misc[0] = a.wend[j];
+		} else {
+			uint32_t m = 0;
+			if (!window_ok) {
+				// ---- general look-back: true state at the start of chain j ----
+				uint32_t c = first;
+				state = j < a.q ? a.init_state : a.end_state[j - a.q];
+				ChainText txt(a, c << a.logS);
+				while (c < j) {
+					if (m == 0 && state == 0) {  // root: merged with chain c's own walk
+						state = a.end_state[c];
+						c++;
+						continue;
+					}
+					m++;
+					// chains are adjacent: step m of chain c is byte (c - first) * S + m - 1
+					state = a.cold[((size_t)state << 8) | txt.at(((c - first) << a.logS) + m)];
+					if (depth_le(a, cum, state, m)) {
+						state = a.end_state[c];
+						c++;
+						m = 0;
+						continue;
+					}
+					if (state >= a.H && state < a.F)
+						m += fast_forward(a, state, (c << a.logS) + m, a.S - m);
+					if (m == a.S) {
+						c++;
+						m = 0;
+					}
 				}
-				if (state >= a.F && base + m - 1 >= a.drop_before) {
-					const uint32_t slot = atomicAdd(&wave_fill[wv], 1u);
-					stage[slot] = make_uint2(base + m - 1, state | (c2 << 24));
-					c2++;
-				}
-				if (!killed && m >= f)
-					killed = true;  // a K1 hit sits in the unmerged head: take the chain over
 			}
+			// ---- head of the own chain, from the true state --------------------
+			const uint32_t base = j << a.logS;
+			const uint32_t len = min(a.S, a.n - base);
+			uint32_t c2 = 0;
+			bool killed = false, merged = (state == 0);
+			if (!merged) {
+				ChainText txt(a, base);
+				for (m = 1; m <= len; m++) {
+					state = a.cold[((size_t)state << 8) | txt.at(m)];
+					if (!killed && depth_le(a, cum, state, m)) {
+						merged = true;
+						break;
+					}
+					if (state >= a.F && base + m - 1 >= a.drop_before) {
+						const uint32_t slot = atomicAdd(&wave_fill[wv], 1u);
+						stage[slot] = make_uint2(base + m - 1, state | (c2 << 24));
+						c2++;
+					}
+					if (!killed && m >= f)
+						killed = true;  // a K1 hit sits in the unmerged head: take the chain over
+					if (state >= a.H && state < a.F) {
+						m += fast_forward(a, state, base + m, len - m);
+						if (!killed && m >= f)
+							killed = true;
+					}
+				}
+			}
+			a.k2info[j] = c2 | (killed ? 0x10000u : 0u);
+			my_cnt = c2 + (killed ? 0u : c1);
+			if (j == a.n_chains - 1)
+				a.misc[0] = merged ? a.end_state[j] : state;
 		}
-		a.k2info[j] = c2 | (killed ? 0x10000u : 0u);
-		a.cnt[j] = (int32_t)(c2 + (killed ? 0u : c1));
-		if (j == a.n_chains - 1)
-			a.misc[0] = merged ? a.end_state[j] : state;
+		a.cnt[j] = (int32_t)my_cnt;
 	}
+	// per-block total of the chain counts, scanned by k_scan_top
+	uint32_t wsum = my_cnt;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		wsum += __shfl_down(wsum, o, 64);
+	if ((threadIdx.x & 63) == 0)
+		wave_sum[wv] = wsum;
 	__syncthreads();
 	if ((threadIdx.x & 63) == 0 && gw * 64 < a.n_chains)
 		a.wave_cnt2[gw] = wave_fill[wv];
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+		for (int w = 0; w < kBlock2 / 64; w++)
+			t += wave_sum[w];
+		a.off[blockIdx.x] = (int32_t)t;
+	}
 }
 
-// records of one staging region -> final planes, one wave per region
-template <bool FROM_K1>
-__global__ __launch_bounds__(256) void k_scatter(ScanArgs a, uint32_t regions, uint32_t chains_per_region)
+// exclusive scan, in place, of the per-block totals by ONE workgroup: each
+// thread owns a contiguous slice, the 1024 slice sums go through a Blelloch
+// up-sweep / down-sweep in LDS.  Also publishes the grand total.
+constexpr int kTopThreads = 1024;
+constexpr uint32_t kTopMax = kTopThreads * 64;
+
+__global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t nb)
 {
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (r >= regions)
-		return;
-	const uint32_t nrec = FROM_K1 ? a.wave_cnt1[r] : a.wave_cnt2[r];
-	const uint2 *stage = (FROM_K1 ? a.stage1 : a.stage2) + (((size_t)r * chains_per_region) << a.logS);
-	for (uint32_t i = lane; i < nrec; i += 64) {
-		const uint2 rec = stage[i];
-		const uint32_t pos = rec.x, st = rec.y & 0xFFFFFFu, seq = rec.y >> 24;
-		const uint32_t j = pos >> a.logS;
-		const uint32_t info = a.k2info[j];
-		uint32_t d = (uint32_t)a.off[j] + seq;
-		if (FROM_K1) {
-			if (info & 0x10000u)
-				continue;
-			d += info & 0xFFFFu;
+	__shared__ int32_t tree[kTopThreads + (kTopThreads >> 5) + 1];
+	const int tid = threadIdx.x;
+	const uint32_t per = (nb + kTopThreads - 1) / kTopThreads;
+	const uint32_t lo = min(nb, (uint32_t)tid * per), hi = min(nb, lo + per);
+	int32_t sum = 0;
+	for (uint32_t i = lo; i < hi; i++)
+		sum += a.off[i];
+	auto pad = [](int i) { return i + (i >> 5); };
+	tree[pad(tid)] = sum;
+	int offset = 1;
+	for (int d = kTopThreads >> 1; d > 0; d >>= 1) {
+		__syncthreads();
+		if (tid < d)
+			tree[pad(offset * (2 * tid + 2) - 1)] += tree[pad(offset * (2 * tid + 1) - 1)];
+		offset <<= 1;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		a.misc[1] = (uint32_t)tree[pad(kTopThreads - 1)];
+		tree[pad(kTopThreads - 1)] = 0;
+	}
+	for (int d = 1; d < kTopThreads; d <<= 1) {
+		offset >>= 1;
+		__syncthreads();
+		if (tid < d) {
+			const int ai = pad(offset * (2 * tid + 1) - 1), bi = pad(offset * (2 * tid + 2) - 1);
+			const int32_t t = tree[ai];
+			tree[ai] = tree[bi];
+			tree[bi] += t;
 		}
-		if (d + 2 < a.plane_capacity) {
-			a.pat_plane[1 + d] = a.out[st];
-			a.off_plane[1 + d] = (int32_t)pos + a.off_shift;
+	}
+	__syncthreads();
+	int32_t run = tree[pad(tid)];
+	for (uint32_t i = lo; i < hi; i++) {
+		const int32_t v = a.off[i];
+		a.off[i] = run;
+		run += v;
+	}
+}
+
+// Ordered scatter of both staging areas + header/trailer cells, one workgroup
+// per 256 chains (the K2b block): scan the block's 256 counts in LDS on top
+// of the block base, then every wave drains one K2 staging region and, while
+// there are any, one K1 wave tile of this block.
+template <int C>
+__global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
+{
+	__shared__ uint32_t off[kBlock2];
+	__shared__ uint32_t wtot[kBlock2 / 64];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t j0 = blockIdx.x * kBlock2, j = j0 + tid;
+	const uint32_t c = j < a.n_chains ? (uint32_t)a.cnt[j] : 0u;
+	// in-wave inclusive scan by shuffles, then add the preceding waves
+	uint32_t inc = c;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(inc, o, 64);
+		if (lane >= (uint32_t)o)
+			inc += t;
+	}
+	if (lane == 63)
+		wtot[wv] = inc;
+	__syncthreads();
+	uint32_t before = (uint32_t)a.off[blockIdx.x];
+	for (uint32_t w = 0; w < wv; w++)
+		before += wtot[w];
+	off[tid] = before + inc - c;
+	__syncthreads();
+
+	auto drain = [&](const uint2 *stage, uint32_t nrec, bool from_k1) {
+		for (uint32_t i = lane; i < nrec; i += 64) {
+			const uint2 rec = stage[i];
+			const uint32_t pos = rec.x, st = rec.y & 0xFFFFFFu, seq = rec.y >> 24;
+			const uint32_t jj = pos >> a.logS;
+			uint32_t d = off[jj - j0] + seq;
+			if (from_k1) {
+				const uint32_t info = a.k2info[jj];
+				if (info & 0x10000u)
+					continue;
+				d += info & 0xFFFFu;
+			}
+			if (d + 2 < a.plane_capacity) {
+				a.pat_plane[1 + d] = a.out[st];
+				a.off_plane[1 + d] = (int32_t)pos + a.off_shift;
+			}
 		}
+	};
+	const uint32_t gw = blockIdx.x * (kBlock2 / 64) + wv;            // K2 staging region
+	if (gw * 64 < a.n_chains)
+		drain(a.stage2 + (((size_t)gw * 64) << a.logS), a.wave_cnt2[gw], false);
+	constexpr uint32_t kTilesPerBlock = kBlock2 / (C * 64);          // K1 wave tiles in this block
+	if (wv < kTilesPerBlock) {
+		const uint32_t wt = blockIdx.x * kTilesPerBlock + wv;
+		if (wt < a.n_tiles)
+			drain(a.stage1 + (((size_t)wt * C * 64) << a.logS), a.wave_cnt1[wt], true);
+	}
+	if (blockIdx.x == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
+		const uint32_t total = a.misc[1];
+		const int32_t last_ref = (int32_t)a.dev2ref[a.misc[0]];
+		uint32_t tail = total + 1;
+		if (tail > a.plane_capacity - 1)
+			tail = a.plane_capacity - 1;
+		a.pat_plane[0] = (int32_t)total;
+		a.off_plane[0] = (int32_t)total;
+		a.pat_plane[tail] = last_ref;
+		a.off_plane[tail] = last_ref;
 	}
 }
 
@@ -362,7 +606,8 @@ __global__ void k_finalize(ScanArgs a, int have_chains)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-	size_t end_state, c1f, k2info, cnt, off, wave_cnt1, wave_cnt2, misc, stage1, stage2, scan_ws;
+	size_t end_state, c1f, k2info, wend, probe, cnt, off, wave_cnt1, wave_cnt2, misc, stage1, stage2,
+	    scan_ws;
 	size_t scan_ws_bytes;
 	size_t total;
 };
@@ -383,6 +628,8 @@ Layout layout_for(size_t max_text)
 	l.end_state = take(chains * 4);
 	l.c1f = take(chains * 4);
 	l.k2info = take(chains * 4);
+	l.wend = take(chains * 4);
+	l.probe = take(chains);
 	l.cnt = take(chains * 4);
 	l.off = take(chains * 4);
 	l.wave_cnt1 = take(waves * 4);
@@ -428,7 +675,7 @@ extern "C" int acm_scan_set_chain_bytes(acm_dfa *d, int chain_bytes)
 	return d->chain_bytes;
 }
 
-extern "C" int acm_scan_kernel_count(void) { return 8; }
+extern "C" int acm_scan_kernel_count(void) { return 5; }
 
 extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, long init_state,
     void *d_workspace, size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
@@ -485,9 +732,13 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.dev2ref = d->d_dev2ref;
 	a.depth_cum = d->d_depth_cum;
 	a.depth_final = d->d_depth_final;
+	a.ffinfo = d->d_ffinfo;
+	a.ref2dev = d->d_ref2dev;
+	a.in_byte = d->d_in_byte;
 	a.text16 = (const uint4 *)d_text;
 	a.text = (const uint8_t *)d_text;
 	a.n = (uint32_t)n;
+	a.n_pad = (uint32_t)((n + 15) & ~(size_t)15);
 	a.S = S;
 	a.logS = logS;
 	a.n_chains = (uint32_t)((n + S - 1) >> logS);
@@ -504,6 +755,8 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.end_state = (uint32_t *)(ws + l.end_state);
 	a.c1f = (uint32_t *)(ws + l.c1f);
 	a.k2info = (uint32_t *)(ws + l.k2info);
+	a.wend = (uint32_t *)(ws + l.wend);
+	a.probe = (uint8_t *)(ws + l.probe);
 	a.cnt = (int32_t *)(ws + l.cnt);
 	a.off = (int32_t *)(ws + l.off);
 	a.wave_cnt1 = (uint32_t *)(ws + l.wave_cnt1);
@@ -538,17 +791,21 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 		return rc;
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
-	hipLaunchKernelGGL(k_resolve, dim3((a.n_chains + kBlock2 - 1) / kBlock2), dim3(kBlock2), 0, s, a);
+	const size_t cum_lds = ((size_t)a.L + 2) * sizeof(uint32_t);
+	hipLaunchKernelGGL(k_probe, dim3((a.n_chains + kBlock2 - 1) / kBlock2), dim3(kBlock2), cum_lds, s, a);
+	hipLaunchKernelGGL(k_resolve, dim3((a.n_chains + kBlock2 - 1) / kBlock2), dim3(kBlock2), cum_lds, s, a);
 	ACM_HIP_TRY(hipGetLastError());
-	rc = acm_exclusive_scan_i32(a.cnt, a.off, a.n_chains, (int32_t *)(a.misc + 1), ws + l.scan_ws,
-	    l.scan_ws_bytes, s);
-	if (rc != ACM_OK)
-		return rc;
-	const uint32_t waves2 = (a.n_chains + 63) / 64;
-	hipLaunchKernelGGL(k_scatter<true>, dim3((a.n_tiles + 3) / 4), dim3(256), 0, s, a, a.n_tiles,
-	    (uint32_t)(C * 64));
-	hipLaunchKernelGGL(k_scatter<false>, dim3((waves2 + 3) / 4), dim3(256), 0, s, a, waves2, 64u);
-	hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, a, 1);
+	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2b blocks == scatter blocks
+	if (nb <= kTopMax) {
+		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kTopThreads), 0, s, a, nb);
+	} else {  // > 16M chains: generic multi-level scan of the block totals
+		rc = acm_exclusive_scan_i32(a.off, a.off, nb, (int32_t *)(a.misc + 1), ws + l.scan_ws,
+		    l.scan_ws_bytes, s);
+		if (rc != ACM_OK)
+			return rc;
+	}
+	static_assert(kBlock2 % (C * 64) == 0, "a scatter block must hold whole K1 wave tiles");
+	hipLaunchKernelGGL(k_scatter_all<C>, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
 	if (d->profile) {
 		ACM_HIP_TRY(hipEventRecord(ev[2], s));
