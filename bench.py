@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
     ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
     ap.add_argument("--plant", type=int, default=4096)
+    ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
+    ap.add_argument("--variant", type=int, default=-1, help="walk kernel: 0 hot rows, 1 bigram, -1 auto")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -83,6 +85,9 @@ def main():
     states = aut.num_states
     matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
     matcher.set_chain_bytes(args.chain)
+    variant = matcher.set_walk_variant(args.variant)
+    if args.cpl:
+        matcher.set_chains_per_lane(args.cpl)
     aut.close()
     log(rank, "automaton: %d sigs, %d states, L=%d, compile %.2fs, device %.1f MB, hot rows %d" % (
         len(pats), states, L, t_compile, matcher.device_bytes / 1e6, matcher.hot_rows))
@@ -243,7 +248,7 @@ def main():
             "parity": parity,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_spec_walk",
+                "kernel": "k_bigram_walk" if variant == 1 else "k_spec_walk",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

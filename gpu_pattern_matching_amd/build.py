@@ -43,6 +43,9 @@ def _stale(target, deps):
 
 def build(force=False, keep_temps=False, verbose=False):
     """Compile every translation unit and link libacmatch.so. Returns its path."""
+    sources = [os.path.join(CSRC, f) for f in SOURCES]
+    if not force and not keep_temps and not _stale(LIB, _deps()):
+        return LIB          # up to date (object files are scratch and need not exist)
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),

@@ -94,6 +94,40 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		for (uint32_t s = a->first_final; s < n; s++)
 			dfin[s - a->first_final] = a->depth[a->dev2ref[s]];
 
+		// bigram image: cells 0..255 = root row; cell 256 + (prev | byte << 8) =
+		// delta(delta(root, prev), byte), 0xFFFF when the id does not fit
+		std::vector<uint16_t> t2(256 + 65536);
+		for (uint32_t c = 0; c < 256; c++)
+			t2[c] = (uint16_t)(rows[c] < acm::kHotSentinel ? rows[c] : acm::kHotSentinel);
+		for (uint32_t prev = 0; prev < 256; prev++) {
+			const uint32_t *row = &rows[(size_t)rows[prev] * 256];
+			for (uint32_t c = 0; c < 256; c++)
+				t2[256 + (prev | (c << 8))] =
+				    (uint16_t)(row[c] < acm::kHotSentinel ? row[c] : acm::kHotSentinel);
+		}
+		// trigram filter: every 3-byte string that is a trie node (depth-3 state)
+		std::vector<uint8_t> bloom(16384, 0);
+		for (uint32_t r = 0; r < n; r++) {
+			if (a->depth[r] != 3)
+				continue;
+			const uint32_t p2 = a->parent[r], p1 = a->parent[p2];
+			const uint32_t tri = (uint32_t)a->in_byte[p1] | ((uint32_t)a->in_byte[p2] << 8) |
+			    ((uint32_t)a->in_byte[r] << 16);
+			const uint32_t h = (((tri * 0x9E3779u) & 0xFFFFFFFFu) >> 15) & (16384 * 8 - 1);
+			bloom[h >> 3] |= (uint8_t)(1u << (h & 7));
+		}
+		d->cum1 = a->depth_cum.size() > 1 ? a->depth_cum[1] : a->depth_cum[0];
+		d->d2lo = a->depth_cum.size() > 1 ? a->depth_cum[1] : a->first_final;
+		d->d2hi = a->depth_cum.size() > 2 ? a->depth_cum[2] : d->d2lo;
+		// the bigram walk pays off when most text bytes lead somewhere from the root
+		// (binary signature sets); word lists keep the BFS hot rows
+		uint32_t firsts = 0;
+		for (uint32_t c = 0; c < 256; c++)
+			firsts += rows[c] != 0;
+		(void)firsts;   // measured on MI355X: the hot-row walk with 4 chains per lane is
+		d->bigram_default = false;   // faster on every fixture so far; bigram stays opt-in
+		d->use_bigram = d->bigram_default;
+
 		std::vector<uint32_t> ffinfo(n);
 		for (uint32_t s = 0; s < n; s++) {
 			const uint32_t r = a->dev2ref[s];
@@ -101,12 +135,22 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		}
 		std::vector<uint8_t> inb(a->in_byte);
 		inb.resize((size_t)n + 32, 0);
+		std::vector<uint8_t> ffr(a->ff_run);
+		ffr.resize((size_t)n + 32, 0);
 
 		rc = upload(&d->d_cold, rows.data(), rows.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_ffinfo, ffinfo.data(), ffinfo.size(), &d->device_bytes);
 		if (rc == ACM_OK)
 			rc = upload(&d->d_ref2dev, a->ref2dev.data(), a->ref2dev.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_ff_run, ffr.data(), ffr.size(), &d->device_bytes);
+		if (rc == ACM_OK) {  // one image: T2 cells, then the filter bytes (LDS copy is one sweep)
+			std::vector<uint16_t> image(t2);
+			image.resize(t2.size() + bloom.size() / 2);
+			memcpy(image.data() + t2.size(), bloom.data(), bloom.size());
+			rc = upload(&d->d_t2, image.data(), image.size(), &d->device_bytes);
+			d->d_bloom = (uint8_t *)(d->d_t2 + t2.size());
+		}
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_out, outp.data(), outp.size(), &d->device_bytes);
 		if (rc == ACM_OK)
@@ -144,6 +188,8 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_ffinfo);
 		hipFree(d->d_ref2dev);
 		hipFree(d->d_in_byte);
+		hipFree(d->d_ff_run);
+		hipFree(d->d_t2);   // d_bloom points into the same allocation
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

@@ -61,6 +61,10 @@ struct ScanArgs {
 	const uint32_t *ffinfo;
 	const uint32_t *ref2dev;
 	const uint8_t *in_byte;
+	const uint8_t *ff_run;  // [ref + 32] unary run length from ref state r
+	const uint16_t *t2;     // bigram table image (root row + 65536 cells), see device_dfa.hip
+	const uint8_t *bloom;   // trigram filter image
+	uint32_t d2lo, d2hi;    // non-final depth-2 dev ids are [d2lo, d2hi)
 	const uint4 *text16;
 	const uint8_t *text;
 	uint32_t n;             // text bytes
@@ -80,7 +84,10 @@ struct ScanArgs {
 	uint32_t *c1f;
 	uint32_t *k2info;
 	uint32_t *wend;         // [chains] end state of the probe walk of chain c from e[c-1]
-	uint8_t *probe;         // [chains] bit0: probe merged, bit1: chain needs an emission walk
+	uint8_t *probe;         // [chains] bit0: probe merged, bit1: chain needs an emission walk;
+	                        //          0xFF: not probed yet (k_probe does it)
+	uint8_t *rflag;         // [chains] 1: the walk kernel already resolved the chain (cnt, k2info set)
+	uint32_t cum1;          // depth_cum[1]: non-final ids below it have depth <= 1
 	int32_t *cnt;
 	int32_t *off;
 	uint32_t *wave_cnt1;
@@ -169,11 +176,86 @@ __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot,
 		st[c] = e[c];
 }
 
+// End of a wave tile: the common case of the boundary resolve, done where the
+// data already is.  Lane l holds e[chain], its left neighbour holds e[chain-1]
+// (a shuffle away), the first text byte of the chain is still in a register
+// and the hot rows are in LDS -- so the probe's first step (does the walk from
+// e[chain-1] merge with this chain's own root walk after one byte?) costs one
+// LDS lookup.  A chain whose probe merges that way, and whose look-back window
+// is made of such chains, is final: count = K1 count, nothing to re-walk.
+// Everything else is left to k_probe / k_resolve through the flag arrays.
+template <int C>
+__device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t *hot, uint32_t wt,
+    uint32_t lane, const uint32_t (&st)[C], const uint32_t (&cnt)[C], const uint32_t (&chain)[C],
+    const uint32_t (&fb)[C])
+{
+	bool decided[C];
+	uint64_t dmask[C];
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		// both shuffles are executed by the whole wave (a shuffle inside a divergent
+		// branch cannot read lanes that did not take the branch)
+		uint32_t pe = __shfl_up(st[c], 1, 64);
+		const uint32_t prev_slot_last = __shfl(st[c > 0 ? c - 1 : 0], 63, 64);
+		bool known = true;
+		if (lane == 0) {
+			if (c > 0)
+				pe = prev_slot_last;
+			else if (chain[c] == 0)
+				pe = a.init_state;
+			else
+				known = false;   // previous chain belongs to another wave
+		}
+		bool ok = false;
+		if (known && chain[c] < a.n_chains) {
+			if (pe == 0) {
+				ok = true;
+			} else if (pe < a.H) {
+				const uint32_t t = hot[(pe << 8) | fb[c]];
+				ok = t < a.cum1;   // non-final, depth <= 1 (a sentinel cell is never < cum1)
+			}
+		}
+		decided[c] = ok;
+		dmask[c] = __builtin_amdgcn_ballot_w64(ok);
+	}
+	const uint32_t window = a.q - 1;   // chains before chain-1 that must have merged too
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		if (chain[c] >= a.n_chains)
+			continue;
+		bool final_here = decided[c] && window <= 32;
+		const int p = c * 64 + (int)lane;   // position inside the tile
+		for (uint32_t k = 1; final_here && k <= window + 0u && k <= 32; k++) {
+			const int pos = p - (int)k;
+			if (pos < 0) {
+				final_here = (wt == 0);   // before the first chain of the text: nothing to check
+				break;
+			}
+			uint64_t mword = dmask[0];
+#pragma unroll
+			for (int cc = 1; cc < C; cc++)
+				mword = (pos >> 6) == cc ? dmask[cc] : mword;
+			final_here = (mword >> (pos & 63)) & 1ull;
+		}
+		// window counts the chains first..j-2; chain j-1 must have merged as well so that
+		// the true start state is e[j-1]: that is bit p-1, covered when window >= 1; for
+		// q == 1 the start state is e[j-1] by construction
+		a.probe[chain[c]] = decided[c] ? 1 : 0xFF;
+		if (decided[c])
+			a.wend[chain[c]] = st[c];
+		a.rflag[chain[c]] = final_here ? 1 : 0;
+		if (final_here) {
+			a.k2info[chain[c]] = 0;
+			a.cnt[chain[c]] = (int32_t)cnt[c];
+		}
+	}
+}
+
 template <int C, bool GUARD>
 __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot, uint32_t wt,
     uint32_t lane)
 {
-	uint32_t st[C], cnt[C], first[C], base[C], len[C], chain[C];
+	uint32_t st[C], cnt[C], first[C], base[C], len[C], chain[C], fb[C];
 	uint32_t wcount = 0;
 	uint2 *stage = a.stage1 + (((size_t)wt * C * 64) << a.logS);
 #pragma unroll
@@ -184,6 +266,7 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 		st[c] = 0;
 		cnt[c] = 0;
 		first[c] = kNoFirst;
+		fb[c] = 0;
 	}
 	const uint32_t groups = a.S >> 4;
 	for (uint32_t g = 0; g < groups; g++) {
@@ -194,6 +277,8 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 				w[c] = a.text16[(base[c] >> 4) + g];
 			else
 				w[c] = make_uint4(0, 0, 0, 0);
+			if (g == 0)
+				fb[c] = w[c].x & 0xFFu;
 		}
 #define ACM_STEP(K) step_all<C, K, GUARD>(a, hot, w, st, cnt, first, base, len, g, wcount, stage)
 		ACM_STEP(0); ACM_STEP(1); ACM_STEP(2); ACM_STEP(3);
@@ -211,6 +296,7 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 	}
 	if (lane == 0)
 		a.wave_cnt1[wt] = wcount;
+	tile_epilogue<C>(a, hot, wt, lane, st, cnt, chain, fb);
 }
 
 // K1: persistent workgroups (one per CU), the hot rows live in LDS for the
@@ -220,11 +306,17 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
 	{
+		// every workgroup copies the same table: start each one at a different
+		// offset so the CUs do not all hit the same L2 channel at the same time
 		const uint4 *src = (const uint4 *)a.hot;
 		uint4 *dst = (uint4 *)hot;
 		const uint32_t n16 = a.H * 32;  // 512 B per row
-		for (uint32_t i = threadIdx.x; i < n16; i += kBlock1)
-			dst[i] = src[i];
+		const uint32_t rot = n16 ? (blockIdx.x * 1021u) % n16 : 0u;
+		for (uint32_t i = threadIdx.x; i < n16; i += kBlock1) {
+			uint32_t j = i + rot;
+			j = j >= n16 ? j - n16 : j;
+			dst[j] = src[j];
+		}
 	}
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
@@ -298,20 +390,242 @@ __device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, uint32_t &st
 	uint32_t run = info >> 24;
 	if (run == 0)
 		return 0;
-	const uint32_t r = info & 0xFFFFFFu;
-	run = min(min(run, limit), 16u);
-	uint64_t e0, e1, t0, t1;
-	__builtin_memcpy(&e0, a.in_byte + r + 1, 8);
-	__builtin_memcpy(&e1, a.in_byte + r + 9, 8);
-	__builtin_memcpy(&t0, a.text + pos, 8);
-	__builtin_memcpy(&t1, a.text + pos + 8, 8);
-	const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
-	uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
-			   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
-	same = min(same, run);
-	if (same)
-		state = a.ref2dev[r + same];
-	return same;
+	uint32_t r = info & 0xFFFFFFu, total = 0;
+	// rounds of up to 16 bytes; after the first one everything a round needs
+	// (ff_run[r], in_byte[r+1..], text) hangs off r alone: one load level per round
+	for (;;) {
+		const uint32_t want = min(min(run, limit - total), 16u);
+		uint64_t e0, e1, t0, t1;
+		__builtin_memcpy(&e0, a.in_byte + r + 1, 8);
+		__builtin_memcpy(&e1, a.in_byte + r + 9, 8);
+		__builtin_memcpy(&t0, a.text + pos + total, 8);
+		__builtin_memcpy(&t1, a.text + pos + total + 8, 8);
+		const uint32_t run_next = a.ff_run[r + 16];   // used only after a full 16-byte round
+		const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
+		uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
+				   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
+		same = min(same, want);
+		r += same;
+		total += same;
+		if (same < 16 || total >= limit || pos + total + 16 > a.n_pad)
+			break;
+		run = run_next;
+		if (run == 0)
+			break;
+	}
+	if (total)
+		state = a.ref2dev[r];
+	return total;
+}
+
+// ---------------------------------------------------------------------------
+// K1, bigram form.  Same contract as k_spec_walk (exact root walk of every
+// chain: end state, staged hits, count, first-hit step) but the common step
+// has NO dependent load:
+//
+//   * LDS holds T2[prev byte][byte] = delta(delta(root, prev), byte): as long
+//     as the true state has depth <= 2, the state after a byte is a pure
+//     function of the last two text bytes, so the lookups of consecutive
+//     bytes are independent and pipeline freely.
+//   * The walk can only leave that regime by stepping from a depth-2 state
+//     to its depth-3 child.  That happens exactly when the last three bytes
+//     are a 3-byte pattern prefix; a trigram filter in LDS (also fed by text
+//     bytes only) flags the candidates.  Only candidates, lanes already deep,
+//     and cells that do not fit 16 bits touch the HBM plane.
+//   * Deep lanes fast-forward along unary trie paths and sit out the skipped
+//     steps, so a lane inside a long signature costs one gather per <= 16
+//     bytes instead of one per byte.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kT2Cells = 256 + 65536;
+constexpr uint32_t kBloomBytes = 16384;                 // 128 Kbit
+constexpr uint32_t kBloomMul = 0x9E3779u;               // 24-bit odd multiplier
+constexpr size_t kBigramLds = kT2Cells * 2 + kBloomBytes;
+
+__device__ __forceinline__ uint32_t bloom_index(uint32_t trigram)
+{
+	return (__umul24(trigram, kBloomMul) >> 15) & (kBloomBytes * 8 - 1);
+}
+
+template <int C, int K, bool GUARD>
+__device__ __forceinline__ void bigram_step(const ScanArgs &a, const uint16_t *t2, const uint8_t *bloom,
+    const uint32_t (&carry)[C], const uint4 (&w)[C], uint32_t (&st)[C], uint32_t (&deep)[C],
+    uint32_t (&skip)[C], uint32_t (&cnt)[C], uint32_t (&first)[C], const uint32_t (&base)[C],
+    const uint32_t (&len)[C], uint32_t g, uint32_t &wcount, uint2 *stage)
+{
+	const uint32_t step = g * 16 + K + 1;   // 1-based; wave-uniform
+	uint32_t v[C], e[C], byte[C];
+	bool need[C], took[C];
+	bool any_need = false;
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		// v = text bytes (i-3, i-2, i-1, i), byte i in the top 8 bits
+		const uint32_t x[5] = { carry[c], w[c].x, w[c].y, w[c].z, w[c].w };
+		constexpr int lo = (K + 1) / 4, sh = (K + 1) % 4;
+		v[c] = sh == 0 ? x[lo] : __builtin_amdgcn_alignbyte(x[lo + 1], x[lo], sh);
+		byte[c] = v[c] >> 24;
+	}
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		const bool first_step = (step == 1);
+		e[c] = t2[first_step ? byte[c] : 256u + (v[c] >> 16)];
+	}
+	uint32_t bit[C];
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		const uint32_t h = bloom_index(v[c] >> 8);
+		bit[c] = (step >= 3) ? ((uint32_t)bloom[h >> 3] >> (h & 7)) & 1u : 0u;
+	}
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		const bool active = !GUARD || step <= len[c];
+		const bool is_d2 = (st[c] - a.d2lo) < (a.d2hi - a.d2lo);
+		const bool cand = (is_d2 && bit[c]) || (st[c] >= a.F && step >= 3);
+		const bool skipping = deep[c] && skip[c] > 0;
+		took[c] = active && !skipping;
+		need[c] = took[c] && (deep[c] || cand || e[c] == acm::kHotSentinel);
+		if (active && skipping)
+			skip[c]--;
+		any_need |= need[c];
+	}
+	if (__builtin_amdgcn_ballot_w64(any_need)) {
+		uint32_t t[C];
+#pragma unroll
+		for (int c = 0; c < C; c++)
+			t[c] = a.cold[need[c] ? ((st[c] << 8) | byte[c]) : 0u];
+#pragma unroll
+		for (int c = 0; c < C; c++) {
+			if (need[c]) {
+				// back in the bigram regime iff the exact state IS the table's value
+				const bool shallow = (t[c] == e[c]) && (e[c] != acm::kHotSentinel);
+				deep[c] = shallow ? 0u : 1u;
+				e[c] = t[c];
+				if (!shallow && t[c] < a.F) {
+					uint32_t s2 = t[c];
+					const uint32_t k = fast_forward(a, s2, base[c] + step, (GUARD ? len[c] : a.S) - step);
+					skip[c] = k;
+					e[c] = s2;           // state after the skipped bytes; none of them is final
+					// the hit test below sees a non-final state, as it must: t[c] < F and
+					// every state entered by the fast-forward is non-final
+				}
+			}
+		}
+	}
+	bool hit[C];
+	bool any_hit = false;
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		if (took[c])
+			st[c] = e[c];
+		hit[c] = took[c] && (e[c] >= a.F);
+		any_hit |= hit[c];
+	}
+	if (__builtin_amdgcn_ballot_w64(any_hit)) {
+#pragma unroll
+		for (int c = 0; c < C; c++) {
+			hit[c] = hit[c] && (base[c] + step - 1 >= a.drop_before);
+			const uint64_t m = __builtin_amdgcn_ballot_w64(hit[c]);
+			if (m) {
+				if (hit[c]) {
+					stage[wcount + mbcnt64(m)] =
+					    make_uint2(base[c] + step - 1, e[c] | (cnt[c] << 24));
+					if (cnt[c] == 0)
+						first[c] = step;
+					cnt[c]++;
+				}
+				wcount += (uint32_t)__popcll(m);
+			}
+		}
+	}
+}
+
+template <int C, bool GUARD>
+__device__ __forceinline__ void bigram_tile(const ScanArgs &a, const uint16_t *t2, const uint8_t *bloom,
+    uint32_t wt, uint32_t lane)
+{
+	uint32_t st[C], deep[C], skip[C], cnt[C], first[C], base[C], len[C], chain[C], carry[C];
+	uint32_t wcount = 0;
+	uint2 *stage = a.stage1 + (((size_t)wt * C * 64) << a.logS);
+	uint4 w[C];
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		chain[c] = (wt * C + c) * 64 + lane;
+		base[c] = chain[c] << a.logS;
+		len[c] = GUARD ? (base[c] >= a.n ? 0u : min(a.S, a.n - base[c])) : a.S;
+		st[c] = 0;
+		deep[c] = 0;
+		skip[c] = 0;
+		cnt[c] = 0;
+		first[c] = kNoFirst;
+		carry[c] = 0;
+		w[c] = (!GUARD || base[c] < a.n) ? a.text16[base[c] >> 4] : make_uint4(0, 0, 0, 0);
+	}
+	const uint32_t groups = a.S >> 4;
+	for (uint32_t g = 0; g < groups; g++) {
+		uint4 wn[C];
+#pragma unroll
+		for (int c = 0; c < C; c++) {  // next group in flight while this one is walked
+			if (g + 1 < groups && (!GUARD || base[c] + (g + 1) * 16 < a.n))
+				wn[c] = a.text16[(base[c] >> 4) + g + 1];
+			else
+				wn[c] = make_uint4(0, 0, 0, 0);
+		}
+#define ACM_BSTEP(K) \
+	bigram_step<C, K, GUARD>(a, t2, bloom, carry, w, st, deep, skip, cnt, first, base, len, g, wcount, stage)
+		ACM_BSTEP(0); ACM_BSTEP(1); ACM_BSTEP(2); ACM_BSTEP(3);
+		ACM_BSTEP(4); ACM_BSTEP(5); ACM_BSTEP(6); ACM_BSTEP(7);
+		ACM_BSTEP(8); ACM_BSTEP(9); ACM_BSTEP(10); ACM_BSTEP(11);
+		ACM_BSTEP(12); ACM_BSTEP(13); ACM_BSTEP(14); ACM_BSTEP(15);
+#undef ACM_BSTEP
+#pragma unroll
+		for (int c = 0; c < C; c++) {
+			carry[c] = w[c].w;
+			w[c] = wn[c];
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < C; c++) {
+		if (chain[c] < a.n_chains) {
+			a.end_state[chain[c]] = st[c];
+			a.c1f[chain[c]] = cnt[c] | (first[c] << 16);
+			a.probe[chain[c]] = 0xFF;   // this variant leaves the whole resolve to K2
+			a.rflag[chain[c]] = 0;
+		}
+	}
+	if (lane == 0)
+		a.wave_cnt1[wt] = wcount;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock1) void k_bigram_walk(ScanArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint16_t t2[];
+	uint8_t *bloom = (uint8_t *)(t2 + kT2Cells);
+	{
+		// T2 and the filter are contiguous in the image (device_dfa.hip).  Every
+		// workgroup copies the same bytes: start each one at a different offset so
+		// the CUs do not all hit the same L2 channel at the same time.
+		const uint4 *src = (const uint4 *)a.t2;
+		uint4 *dst = (uint4 *)t2;
+		constexpr uint32_t n16 = (uint32_t)(kBigramLds / 16);
+		const uint32_t rot = (blockIdx.x * 1021u) % n16;
+		for (uint32_t i = threadIdx.x; i < n16; i += kBlock1) {
+			uint32_t j = i + rot;
+			j = j >= n16 ? j - n16 : j;
+			dst[j] = src[j];
+		}
+	}
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = blockIdx.x * kWaves1 + (threadIdx.x >> 6);
+	const uint32_t nwaves = gridDim.x * kWaves1;
+	const uint32_t tile_bytes = (C * 64u) << a.logS;
+	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
+		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n;
+		if (full)
+			bigram_tile<C, false>(a, t2, bloom, wt, lane);
+		else
+			bigram_tile<C, true>(a, t2, bloom, wt, lane);
+	}
 }
 
 // K2a probe: lane c walks chain c from e[c-1] (the state chain c would start
@@ -327,6 +641,8 @@ __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 	const uint32_t c = blockIdx.x * kBlock2 + threadIdx.x;
 	if (c >= a.n_chains)
 		return;
+	if (a.probe[c] != 0xFF)
+		return;   // the walk kernel already did this chain's probe in its epilogue
 	uint32_t s = c == 0 ? a.init_state : a.end_state[c - 1];
 	const uint32_t base = c << a.logS;
 	const uint32_t len = min(a.S, a.n - base);
@@ -370,7 +686,11 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 	uint2 *stage = a.stage2 + (((size_t)gw * 64) << a.logS);
 	uint32_t my_cnt = 0;
 
-	if (j < a.n_chains) {
+	if (j < a.n_chains && a.rflag[j]) {
+		my_cnt = (uint32_t)a.cnt[j];   // resolved by the walk kernel's epilogue
+		if (j == a.n_chains - 1)
+			a.misc[0] = a.wend[j];
+	} else if (j < a.n_chains) {
 		const uint32_t info = a.c1f[j];
 		const uint32_t c1 = info & 0xFFFFu, f = info >> 16;
 		const uint32_t first = j < a.q ? 0u : j - a.q + 1;   // first chain the look-back walks
@@ -393,10 +713,37 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 				// ---- general look-back: true state at the start of chain j ----
 				uint32_t c = first;
 				state = j < a.q ? a.init_state : a.end_state[j - a.q];
-				ChainText txt(a, c << a.logS);
+				{
+					// Wherever the walk enters chain c in the state its probe assumed
+					// (e[c-1]), the probe's end state wend[c] is the answer.  Fetch the
+					// window's pairs with independent loads and consume them from
+					// registers, instead of a load-compare-load chain per chain.
+					constexpr uint32_t W = 8;
+					const uint32_t nwin = j - first;
+					uint32_t pe[W], pw[W];
+#pragma unroll
+					for (uint32_t i = 0; i < W; i++) {
+						const uint32_t cc = first + i;
+						const bool in = i < nwin && nwin <= W;
+						pe[i] = in ? (cc == 0 ? a.init_state : a.end_state[cc - 1]) : 0xFFFFFFFFu;
+						pw[i] = in ? a.wend[cc] : 0u;
+					}
+#pragma unroll
+					for (uint32_t i = 0; i < W; i++)
+						if (c == first + i && state == pe[i]) {
+							state = pw[i];
+							c++;
+						}
+				}
+				ChainText txt(a, first << a.logS);
 				while (c < j) {
 					if (m == 0 && state == 0) {  // root: merged with chain c's own walk
 						state = a.end_state[c];
+						c++;
+						continue;
+					}
+					if (m == 0 && state == (c == 0 ? a.init_state : a.end_state[c - 1])) {
+						state = a.wend[c];       // exactly the walk the probe of chain c did
 						c++;
 						continue;
 					}
@@ -606,7 +953,7 @@ __global__ void k_finalize(ScanArgs a, int have_chains)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-	size_t end_state, c1f, k2info, wend, probe, cnt, off, wave_cnt1, wave_cnt2, misc, stage1, stage2,
+	size_t end_state, c1f, k2info, wend, probe, rflag, cnt, off, wave_cnt1, wave_cnt2, misc, stage1, stage2,
 	    scan_ws;
 	size_t scan_ws_bytes;
 	size_t total;
@@ -630,6 +977,7 @@ Layout layout_for(size_t max_text)
 	l.k2info = take(chains * 4);
 	l.wend = take(chains * 4);
 	l.probe = take(chains);
+	l.rflag = take(chains);
 	l.cnt = take(chains * 4);
 	l.off = take(chains * 4);
 	l.wave_cnt1 = take(waves * 4);
@@ -641,6 +989,19 @@ Layout layout_for(size_t max_text)
 	l.scan_ws = take(l.scan_ws_bytes);
 	l.total = o;
 	return l;
+}
+
+template <int C>
+int launch_bigram_walk(const ScanArgs &a, int num_cus, hipStream_t s)
+{
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_bigram_walk<C>,
+	    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigramLds));
+	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
+	if (blocks > (uint32_t)num_cus)
+		blocks = (uint32_t)num_cus;
+	hipLaunchKernelGGL(k_bigram_walk<C>, dim3(blocks), dim3(kBlock1), kBigramLds, s, a);
+	ACM_HIP_TRY(hipGetLastError());
+	return ACM_OK;
 }
 
 template <int C>
@@ -677,6 +1038,26 @@ extern "C" int acm_scan_set_chain_bytes(acm_dfa *d, int chain_bytes)
 
 extern "C" int acm_scan_kernel_count(void) { return 5; }
 
+extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
+{
+	if (!d)
+		return 0;
+	if (chains == 2 || chains == 4)
+		d->chains_per_lane = chains;
+	return d->chains_per_lane;
+}
+
+extern "C" int acm_scan_set_walk_variant(acm_dfa *d, int variant)
+{
+	if (!d)
+		return -1;
+	if (variant == 0 || variant == 1)
+		d->use_bigram = variant == 1;
+	else if (variant == -1)
+		d->use_bigram = d->bigram_default;
+	return d->use_bigram ? 1 : 0;
+}
+
 extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, long init_state,
     void *d_workspace, size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
     size_t plane_capacity, void *stream)
@@ -711,7 +1092,7 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 
 	// geometry: enough chains to give every lane of every CU work, chains
 	// as long as that allows (longer chains = fewer look-back steps)
-	constexpr int C = 2;
+	const int C = d->chains_per_lane == 4 ? 4 : 2;   // chains a lane interleaves in the walk kernel
 	uint32_t S = (uint32_t)d->chain_bytes;
 	if (S == 0) {
 		const size_t lanes = (size_t)d->num_cus * kBlock1 * C;
@@ -735,6 +1116,11 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.ffinfo = d->d_ffinfo;
 	a.ref2dev = d->d_ref2dev;
 	a.in_byte = d->d_in_byte;
+	a.ff_run = d->d_ff_run;
+	a.t2 = d->d_t2;
+	a.bloom = d->d_bloom;
+	a.d2lo = d->d2lo;
+	a.d2hi = d->d2hi;
 	a.text16 = (const uint4 *)d_text;
 	a.text = (const uint8_t *)d_text;
 	a.n = (uint32_t)n;
@@ -757,6 +1143,8 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.k2info = (uint32_t *)(ws + l.k2info);
 	a.wend = (uint32_t *)(ws + l.wend);
 	a.probe = (uint8_t *)(ws + l.probe);
+	a.rflag = (uint8_t *)(ws + l.rflag);
+	a.cum1 = d->cum1;
 	a.cnt = (int32_t *)(ws + l.cnt);
 	a.off = (int32_t *)(ws + l.off);
 	a.wave_cnt1 = (uint32_t *)(ws + l.wave_cnt1);
@@ -786,7 +1174,11 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 		}
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	}
-	int rc = launch_spec_walk<C>(a, d->num_cus, s);
+	int rc;
+	if (C == 4)
+		rc = d->use_bigram ? launch_bigram_walk<4>(a, d->num_cus, s) : launch_spec_walk<4>(a, d->num_cus, s);
+	else
+		rc = d->use_bigram ? launch_bigram_walk<2>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
 	if (rc != ACM_OK)
 		return rc;
 	if (d->profile)
@@ -804,8 +1196,11 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 		if (rc != ACM_OK)
 			return rc;
 	}
-	static_assert(kBlock2 % (C * 64) == 0, "a scatter block must hold whole K1 wave tiles");
-	hipLaunchKernelGGL(k_scatter_all<C>, dim3(nb), dim3(kBlock2), 0, s, a);
+	static_assert(kBlock2 % (4 * 64) == 0, "a scatter block must hold whole K1 wave tiles");
+	if (C == 4)
+		hipLaunchKernelGGL(k_scatter_all<4>, dim3(nb), dim3(kBlock2), 0, s, a);
+	else
+		hipLaunchKernelGGL(k_scatter_all<2>, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
 	if (d->profile) {
 		ACM_HIP_TRY(hipEventRecord(ev[2], s));

@@ -160,6 +160,15 @@ int acm_scan_shard_async(const acm_dfa *, const void *d_text, size_t n,
  * lane walks per tile (power of two, 16..256).  Returns the value in use. */
 int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
 
+/* independent chains each lane interleaves in the walk kernel: 2 or 4.
+ * Returns the value in use. */
+int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
+
+/* walk kernel variant: 0 = BFS hot rows in LDS (k_spec_walk), 1 = bigram
+ * table + trigram filter in LDS (k_bigram_walk), -1 = the automatic choice
+ * made at upload.  Returns the variant in use.  Results are identical. */
+int acm_scan_set_walk_variant(acm_dfa *, int variant);
+
 /* number of kernels one acm_scan_async enqueues for a non-empty text */
 int acm_scan_kernel_count(void);
 
