@@ -6,11 +6,14 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): input GB/s scanned (+ matches/s), 32 MB text x N ClamAV signatures.
-A step = one pass of the scan pipeline (walk -> resolve -> prefix sum -> scatter) over one
-32 MiB batch already resident in HBM; with N > 1 GPUs the logical text is N x 32 MiB, rank g
-scans shard g (+ an (L-1)-byte halo), the DFA is replicated and every step ends with the RCCL
-gather of the compact match planes to rank 0 (double-buffered, overlapped with the next
-step's scan).  Weak scaling: 32 MiB per GPU.
+A step = one pass of the scan pipeline (walk -> probe -> resolve -> prefix sum -> scatter) over
+one 32 MiB batch already resident in HBM.  Like the reference, which keeps -w worker threads in
+flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144, :498-502),
+steps are issued round-robin on --workers HIP streams with private scratch, so the
+latency-bound tail of one batch overlaps the walk of the next.  With N > 1 GPUs the logical
+text is N x 32 MiB, rank g scans shard g (+ an (L-1)-byte halo), the DFA is replicated and
+every step ends with the RCCL gather of the compact match planes to rank 0 (double-buffered).
+Weak scaling: 32 MiB per GPU.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,8 +47,8 @@ def main():
     ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
     ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
     ap.add_argument("--plant", type=int, default=4096)
+    ap.add_argument("--workers", type=int, default=2, help="batches in flight (HIP streams)")
     ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
-    ap.add_argument("--variant", type=int, default=-1, help="walk kernel: 0 hot rows, 1 bigram, -1 auto")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -85,7 +88,6 @@ def main():
     states = aut.num_states
     matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
     matcher.set_chain_bytes(args.chain)
-    variant = matcher.set_walk_variant(args.variant)
     if args.cpl:
         matcher.set_chains_per_lane(args.cpl)
     aut.close()
@@ -106,31 +108,41 @@ def main():
     d_text = torch.zeros((n_local + 15) // 16 * 16, dtype=torch.uint8, device=dev)
     d_text[:n_local] = torch.from_numpy(mine).to(dev)
     ws_bytes = matcher.lib.acm_scan_workspace_bytes(matcher.dfa, n_local)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     cap = 1 << 16                                   # cells per plane; 3.8k records expected
-    planes = [torch.zeros((2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-    pending = [None, None]
+    W = max(1, args.workers)
+
+    class Worker:
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev)
+            self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            self.planes = [torch.zeros((2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+            self.pending = [None, None]
+            self.gathered = [[torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
+                             for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+
+    workers = [Worker() for _ in range(W)]
+    torch.cuda.synchronize()
 
     def step(k):
-        buf = k & 1
-        if pending[buf] is not None:                # the gather that last used this buffer
-            pending[buf].wait()
-            pending[buf] = None
-        p = planes[buf]
-        matcher.scan_async(d_text, n_local, 0, stream, p[0], p[1], cap, halo=plan["halo"],
-                           offset_shift=plan["offset_shift"], workspace=(ws, ws_bytes))
+        wk = workers[k % W]
+        buf = (k // W) & 1
+        if wk.pending[buf] is not None:             # the gather that last used this buffer
+            wk.pending[buf].wait()
+            wk.pending[buf] = None
+        p = wk.planes[buf]
+        matcher.scan_async(d_text, n_local, 0, wk.stream.cuda_stream, p[0], p[1], cap, halo=plan["halo"],
+                           offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes))
         if world > 1:
-            bufs = gathered[buf] if rank == 0 else None
-            pending[buf] = dist.gather(p, gather_list=bufs, dst=0, async_op=True)
-
-    gathered = [[torch.empty_like(planes[0]) for _ in range(world)] for _ in range(2)] \
-        if (world > 1 and rank == 0) else [None, None]
+            with torch.cuda.stream(wk.stream):
+                wk.pending[buf] = dist.gather(p, gather_list=wk.gathered[buf] if rank == 0 else None,
+                                              dst=0, async_op=True)
 
     def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        for wk in workers:
+            for b in (0, 1):
+                if wk.pending[b] is not None:
+                    wk.pending[b].wait()
+                    wk.pending[b] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -158,8 +170,9 @@ def main():
         elapsed = float(t.item())
 
     # ---- results of the last step -------------------------------------------------------------
-    last = (args.steps - 1) & 1 if args.steps > 0 else 0
-    local = planes[last].cpu().numpy()
+    k_last = max(args.steps - 1, 0)
+    wk_last, last = workers[k_last % W], (k_last // W) & 1
+    local = wk_last.planes[last].cpu().numpy()
     m_local = int(local[0, 0])
     m_total = m_local
     if world > 1:
@@ -170,7 +183,7 @@ def main():
     out = None
     if rank == 0:
         if world > 1:
-            offs, pids, last_state = sharding.merge_gathered(gathered[last])
+            offs, pids, last_state = sharding.merge_gathered(wk_last.gathered[last])
         else:
             offs, pids, last_state = sharding.merge_gathered([local])
         assert offs.size == m_total
@@ -214,10 +227,15 @@ def main():
         alg_bytes = n_local + 8 * m_local
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         value = total_bytes * args.steps / elapsed / 1e9
+        # HBM bytes per launch of the walk kernel from the PMC passes of this same command
+        # (tests/run_pmc.sh -> tests/pmc_summarize.py -> profiles/r1_traffic.json); counters
+        # cannot be collected inside a timed run, so this is read back, never estimated
         traffic = None
-        tpath = os.environ.get("ACM_HBM_TRAFFIC_BYTES")     # per-launch PMC figure, see profiles/
-        if tpath:
-            traffic = float(tpath)
+        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tfile) and args.sigs == 2000 and args.max_len < 0:
+            for kname, rec in json.load(open(tfile)).items():
+                if "k_spec_walk" in kname:
+                    traffic = round(rec["hbm_bytes_per_launch"], 1)
         out = {
             "metric": "input_GB_per_s_scanned",
             "value": round(value, 3),
@@ -240,6 +258,7 @@ def main():
                 "text_bytes_per_gpu": SHARD,
                 "signatures": args.sigs,
                 "chain_bytes": matcher.set_chain_bytes(args.chain) or "auto",
+                "batches_in_flight": W,
                 "parallelism": "text sharded %d-way, DFA replicated" % world,
             },
             "matches_per_step": m_total,
@@ -248,7 +267,7 @@ def main():
             "parity": parity,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_bigram_walk" if variant == 1 else "k_spec_walk",
+                "kernel": "k_spec_walk",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

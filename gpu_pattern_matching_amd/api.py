@@ -175,10 +175,6 @@ class Matcher:
     def set_chains_per_lane(self, c):
         return self.lib.acm_scan_set_chains_per_lane(self.dfa, c)
 
-    def set_walk_variant(self, v):
-        """0 = BFS hot rows, 1 = bigram table + trigram filter, -1 = automatic."""
-        return self.lib.acm_scan_set_walk_variant(self.dfa, v)
-
     def scan_async(self, d_text, n, init_state=0, stream=None, pat_plane=None, off_plane=None,
                    plane_capacity=None, halo=0, offset_shift=0, workspace=None):
         """Enqueue one scan of device text; nothing is synchronised.

@@ -36,9 +36,15 @@ constexpr uint32_t kNoPattern = 0xFFFFFFFFu;
 // Host automaton.  States carry two numberings:
 //   ref id : the reference's creation order (acsmx.c:339-344), used at the
 //            API boundary (last_state, acsm_get_states, table export)
-//   dev id : non-final states in BFS order, then final states in BFS order;
-//            "final" == id >= first_final, "depth <= m" == id < depth_cum[m]
-//            for non-final ids.  Root is dev id 0.
+//   dev id : [0, hot_count)        the first non-final states in BFS order
+//                                  (root, depth 1, ...): the rows the walk
+//                                  kernel keeps in LDS;
+//            [hot_count, first_final)  every other non-final state, in ref
+//                                  order -- states created by one pattern
+//                                  insertion are consecutive, so a unary trie
+//                                  path is a run of consecutive dev ids;
+//            [first_final, n)      final states, in ref order.
+//            "final" == id >= first_final.  Root is dev id 0.
 struct acm_automaton {
 	struct Pattern {
 		std::vector<unsigned char> bytes;
@@ -67,21 +73,20 @@ struct acm_automaton {
 	std::vector<int32_t> list_pool;
 
 	std::vector<uint32_t> ref2dev, dev2ref;
+	uint32_t hot_count = 0;                // dev ids below this are the LDS rows
+	uint32_t hot_depth1 = 1;               // hot dev ids below this have depth <= 1
 	uint32_t first_final = 0;              // dev ids >= this are final
-	std::vector<uint32_t> depth_cum;       // [m] non-final states with depth <= m, m = 0..max_len
 	std::vector<int32_t> next_chained;     // [pattern] acsm_get_patterns_table chain
-	// fast-forward along unary trie paths: ref ids are consecutive along the
-	// states one pattern insertion creates (acsmx.c:339-344), so from ref
-	// state r the next ff_run[r] states are r+1, r+2, ... reached on bytes
-	// in_byte[r+1], in_byte[r+2], ... -- each with exactly one child and
-	// none of them final.  Lets the deep walks compare 16 text bytes per
-	// dependent load instead of one table lookup per byte.
-	std::vector<uint8_t> ff_run;           // [ref], capped at 255
+	// dev_run[d]: how many steps d -> d+1 -> ... follow the trie: d+1 is the
+	// ONLY child of d and is not final.  Along such a run the walk only has
+	// to compare text with in_byte of the states ahead -- 16 bytes per load.
+	std::vector<uint16_t> dev_run;         // [dev]
 
-	// dense DFA, dev numbering, [num_states][256]; built on first use
-	mutable std::vector<uint32_t> dense;
-	const std::vector<uint32_t> &dense_rows() const;
-	void drop_dense() const { std::vector<uint32_t>().swap(dense); }
+	// dense DFA, dev numbering, [num_states][256] cells; built on first use.
+	// cell = target dev id | depth(target) << 32 | dev_run[target] << 48
+	mutable std::vector<uint64_t> dense;
+	const std::vector<uint64_t> &dense_rows() const;
+	void drop_dense() const { std::vector<uint64_t>().swap(dense); }
 
 	int head_of(uint32_t ref) const
 	{

@@ -328,51 +328,57 @@ struct Builder {
 			a.list_pool.push_back(own[s][k]);
 	}
 
-	// dev ids: non-final states in BFS order, then final states in BFS
-	// order.  The root is never final: a transition into state 0 cannot be
-	// flagged because the reference stores finals as -state (acsmx.c:645).
+	// dev ids: hot rows first (the first non-final states in BFS order), then
+	// the other non-final states and the final states, both in ref order.
+	// The root is never final: a transition into state 0 cannot be flagged
+	// because the reference stores finals as -state (acsmx.c:645).
 	void number_for_device()
 	{
-		uint32_t n = a.num_states;
-		a.ref2dev.assign(n, 0);
+		const uint32_t n = a.num_states;
+		a.ref2dev.assign(n, UINT32_MAX);
 		a.dev2ref.assign(n, 0);
 		uint32_t next = 0;
-		for (uint32_t s : a.bfs_order)
-			if (!a.is_final_ref(s)) {
+		a.hot_depth1 = 0;
+		for (uint32_t s : a.bfs_order) {
+			if (next >= acm::kHotRowsMax)
+				break;
+			if (a.is_final_ref(s))
+				continue;
+			if (a.depth[s] <= 1)
+				a.hot_depth1 = next + 1;
+			a.ref2dev[s] = next;
+			a.dev2ref[next++] = s;
+		}
+		a.hot_count = next;
+		for (uint32_t s = 0; s < n; s++)
+			if (a.ref2dev[s] == UINT32_MAX && !a.is_final_ref(s)) {
 				a.ref2dev[s] = next;
 				a.dev2ref[next++] = s;
 			}
 		a.first_final = next;
-		for (uint32_t s : a.bfs_order)
-			if (a.is_final_ref(s)) {
+		for (uint32_t s = 0; s < n; s++)
+			if (a.ref2dev[s] == UINT32_MAX) {
 				a.ref2dev[s] = next;
 				a.dev2ref[next++] = s;
 			}
-		int L = a.max_pattern_len;
-		a.depth_cum.assign((size_t)L + 2, 0);
-		for (uint32_t s = 0; s < n; s++)
-			if (!a.is_final_ref(s))
-				a.depth_cum[a.depth[s]]++;
-		for (int m = 1; m <= L + 1; m++)
-			a.depth_cum[m] += a.depth_cum[m - 1];
 	}
 
-	// ff_run[r]: how many steps r -> r+1 -> ... stay on a path where the
-	// state left has exactly one child (the next ref id) and the state
-	// entered is not final.  Computed right to left.
+	// dev_run[d]: length of the unary, non-final path d -> d+1 -> d+2 ...
+	// Computed right to left over dev ids.
 	void unary_runs()
 	{
 		const uint32_t n = a.num_states;
-		a.ff_run.assign(n, 0);
-		for (uint32_t r = n; r-- > 0;) {
-			if (r + 1 >= n)
+		a.dev_run.assign(n, 0);
+		for (uint32_t d = n; d-- > 0;) {
+			if (d + 1 >= a.first_final || d == 0)
+				continue;   // the state entered must not be final; the root has no run
+			const uint32_t r = a.dev2ref[d], r1 = a.dev2ref[d + 1];
+			const bool only_child = a.child_begin[r + 1] - a.child_begin[r] == 1 &&
+			    a.child_list[a.child_begin[r]].to == r1;
+			if (!only_child)
 				continue;
-			const bool one_child = a.child_begin[r + 1] - a.child_begin[r] == 1 &&
-			    a.child_list[a.child_begin[r]].to == r + 1;
-			if (!one_child || a.is_final_ref(r + 1) || r == 0)
-				continue;
-			const uint32_t next = a.ff_run[r + 1];
-			a.ff_run[r] = (uint8_t)(next >= 254 ? 255 : next + 1);
+			const uint32_t nx = a.dev_run[d + 1];
+			a.dev_run[d] = (uint16_t)(nx >= 65534 ? 65535 : nx + 1);
 		}
 	}
 
@@ -434,19 +440,25 @@ extern "C" int acm_automaton_compile(acm_automaton *a)
 }
 
 // Dense rows in BFS order: row(s) = row(fail(s)) with the trie children of s
-// written over it; the root row is all zeros plus its children.  fail(s) is
-// shallower than s, so its row exists by the time s is reached.
-const std::vector<uint32_t> &acm_automaton::dense_rows() const
+// written over it; the root row is all "-> root" plus its children.  fail(s)
+// is shallower than s, so its row exists by the time s is reached.  A cell
+// carries everything the deep walks need to know about its target.
+const std::vector<uint64_t> &acm_automaton::dense_rows() const
 {
 	if (!dense.empty() || num_states == 0)
 		return dense;
-	dense.assign((size_t)num_states * 256, 0);
+	std::vector<uint64_t> cell(num_states);
+	for (uint32_t r = 0; r < num_states; r++) {
+		const uint32_t d = ref2dev[r];
+		cell[r] = (uint64_t)d | ((uint64_t)depth[r] << 32) | ((uint64_t)dev_run[d] << 48);
+	}
+	dense.assign((size_t)num_states * 256, cell[0]);
 	for (uint32_t s : bfs_order) {
-		uint32_t *row = &dense[(size_t)ref2dev[s] * 256];
+		uint64_t *row = &dense[(size_t)ref2dev[s] * 256];
 		if (s != 0)
-			memcpy(row, &dense[(size_t)ref2dev[fail[s]] * 256], 256 * sizeof(uint32_t));
+			memcpy(row, &dense[(size_t)ref2dev[fail[s]] * 256], 256 * sizeof(uint64_t));
 		for (uint32_t e = child_begin[s]; e < child_begin[s + 1]; e++)
-			row[child_list[e].byte] = ref2dev[child_list[e].to];
+			row[child_list[e].byte] = cell[child_list[e].to];
 	}
 	return dense;
 }
@@ -478,13 +490,14 @@ extern "C" int acm_automaton_export_reference_table(const acm_automaton *a, int3
 	if (!a || !a->compiled || !dst)
 		return acm::fail(ACM_ERR_ARG, "export_reference_table: automaton not compiled");
 	try {
-		const std::vector<uint32_t> &rows = a->dense_rows();
+		const std::vector<uint64_t> &rows = a->dense_rows();
 		for (uint32_t s = 0; s < a->num_states; s++) {
-			const uint32_t *row = &rows[(size_t)a->ref2dev[s] * 256];
+			const uint64_t *row = &rows[(size_t)a->ref2dev[s] * 256];
 			int32_t *out = dst + (size_t)s * 512;
 			for (int c = 0; c < 256; c++) {
-				uint32_t t = a->dev2ref[row[c]];
-				if (row[c] >= a->first_final) {
+				const uint32_t td = (uint32_t)row[c];
+				uint32_t t = a->dev2ref[td];
+				if (td >= a->first_final) {
 					out[c] = -(int32_t)t;
 					out[256 + c] = a->head_of(t);
 				} else {

@@ -2,26 +2,28 @@
 //
 // Replaces the d_trans half of acsm_gen_state_table (acsmx.c:618-666).  The
 // reference ships one int32 [state][2][256] table (2 KiB per state, final
-// transitions stored negated, pattern index in a second plane).  Here:
+// transitions stored negated, pattern index in a second plane).  Here, in the
+// device numbering of acm_internal.h (hot rows, other non-finals in reference
+// order, finals last):
 //
-//   cold   u32 [states][256]   next state, dev numbering, 1 KiB rows.  Final
-//                              states are numbered last, so "transition is
-//                              final" is  next >= first_final  -- no flag
-//                              bits, no second plane.
-//   hot    u16 [H][256]        the first H (<= 256) non-final states in BFS
-//                              order (root, depth 1, ...): copied to LDS by
-//                              the scan kernel.  A cell holds the next state,
-//                              or 0xFFFF when it does not fit (then the lane
-//                              reads the cold plane).
-//   out    i32 [states]        pattern index a final state reports (the head
-//                              of its match list, acsmx.c:650), -1 otherwise
-//   dev2ref u32 [states]       back to the reference's numbering (last_state)
-//   depth_cum u32 [L+2]        non-final ids < depth_cum[m]  <=>  depth <= m
-//   depth_final u16 [finals]   depth of final state first_final + i
-//   ffinfo u32 [states], ref2dev u32 [states], in_byte u8 [states]:
-//                              fast-forward along unary trie paths for the
-//                              deep walks of the resolve stage (ref ids are
-//                              consecutive along such a path)
+//   cold   u32 [states][256]    1 KiB rows, next state; "the transition is
+//                               final" is  next >= first_final  -- no flag
+//                               bits.  The walk kernel reads only this plane.
+//   meta   u32 [states][256]    depth(next) | run(next) << 16, same index: what
+//                               the boundary-resolve walks need about the state
+//                               they just entered (merge test, fast-forward)
+//                               comes back in the same load level as the state.
+//   hot    u16 [H][256]         rows of the first H (<= 256) non-final states
+//                               in BFS order (root, depth 1, ...): copied to
+//                               LDS by the walk kernel.  A cell holds the next
+//                               state, or 0xFFFF when it does not fit or is
+//                               final (the lane then reads the cold plane).
+//   out    i32 [states]         pattern index a final state reports (the head
+//                               of its match list, acsmx.c:650), -1 otherwise
+//   dev2ref u32 [states]        back to the reference's numbering (last_state)
+//   in_byte u8 [states + 32]    byte on the trie edge into each state; along
+//                               a unary path the states ahead are d+1, d+2, ...
+//                               so 16 expected bytes are one contiguous load
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -70,96 +72,43 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 	d->device = device;
 	d->num_states = a->num_states;
 	d->first_final = a->first_final;
+	d->hot_rows = a->hot_count;
+	d->hot_depth1 = a->hot_depth1;
 	d->max_pattern_len = (uint32_t)a->max_pattern_len;
 	d->ref2dev = a->ref2dev;
-	d->dev2ref_host = a->dev2ref;
 
 	int rc = ACM_OK;
 	try {
-		const std::vector<uint32_t> &rows = a->dense_rows();
-		uint32_t n = a->num_states;
+		const std::vector<uint64_t> &rows = a->dense_rows();
+		const uint32_t n = a->num_states, H = a->hot_count, F = a->first_final;
 
-		uint32_t H = a->first_final < acm::kHotRowsMax ? a->first_final : acm::kHotRowsMax;
 		std::vector<uint16_t> hot((size_t)H * 256);
-		for (size_t i = 0; i < hot.size(); i++)
-			hot[i] = (uint16_t)(rows[i] < acm::kHotSentinel ? rows[i] : acm::kHotSentinel);
-		d->hot_rows = H;
-
+		for (size_t i = 0; i < hot.size(); i++) {
+			const uint32_t t = (uint32_t)rows[i];
+			hot[i] = (uint16_t)((t < acm::kHotSentinel && t < F) ? t : acm::kHotSentinel);
+		}
 		std::vector<int32_t> outp(n);
-		for (uint32_t s = 0; s < n; s++) {
-			uint32_t r = a->dev2ref[s];
-			outp[s] = a->is_final_ref(r) ? a->head_of(r) : -1;
-		}
-		std::vector<uint16_t> dfin(n - a->first_final);
-		for (uint32_t s = a->first_final; s < n; s++)
-			dfin[s - a->first_final] = a->depth[a->dev2ref[s]];
-
-		// bigram image: cells 0..255 = root row; cell 256 + (prev | byte << 8) =
-		// delta(delta(root, prev), byte), 0xFFFF when the id does not fit
-		std::vector<uint16_t> t2(256 + 65536);
-		for (uint32_t c = 0; c < 256; c++)
-			t2[c] = (uint16_t)(rows[c] < acm::kHotSentinel ? rows[c] : acm::kHotSentinel);
-		for (uint32_t prev = 0; prev < 256; prev++) {
-			const uint32_t *row = &rows[(size_t)rows[prev] * 256];
-			for (uint32_t c = 0; c < 256; c++)
-				t2[256 + (prev | (c << 8))] =
-				    (uint16_t)(row[c] < acm::kHotSentinel ? row[c] : acm::kHotSentinel);
-		}
-		// trigram filter: every 3-byte string that is a trie node (depth-3 state)
-		std::vector<uint8_t> bloom(16384, 0);
-		for (uint32_t r = 0; r < n; r++) {
-			if (a->depth[r] != 3)
-				continue;
-			const uint32_t p2 = a->parent[r], p1 = a->parent[p2];
-			const uint32_t tri = (uint32_t)a->in_byte[p1] | ((uint32_t)a->in_byte[p2] << 8) |
-			    ((uint32_t)a->in_byte[r] << 16);
-			const uint32_t h = (((tri * 0x9E3779u) & 0xFFFFFFFFu) >> 15) & (16384 * 8 - 1);
-			bloom[h >> 3] |= (uint8_t)(1u << (h & 7));
-		}
-		d->cum1 = a->depth_cum.size() > 1 ? a->depth_cum[1] : a->depth_cum[0];
-		d->d2lo = a->depth_cum.size() > 1 ? a->depth_cum[1] : a->first_final;
-		d->d2hi = a->depth_cum.size() > 2 ? a->depth_cum[2] : d->d2lo;
-		// the bigram walk pays off when most text bytes lead somewhere from the root
-		// (binary signature sets); word lists keep the BFS hot rows
-		uint32_t firsts = 0;
-		for (uint32_t c = 0; c < 256; c++)
-			firsts += rows[c] != 0;
-		(void)firsts;   // measured on MI355X: the hot-row walk with 4 chains per lane is
-		d->bigram_default = false;   // faster on every fixture so far; bigram stays opt-in
-		d->use_bigram = d->bigram_default;
-
-		std::vector<uint32_t> ffinfo(n);
+		std::vector<uint8_t> inb((size_t)n + 32, 0);
 		for (uint32_t s = 0; s < n; s++) {
 			const uint32_t r = a->dev2ref[s];
-			ffinfo[s] = r | ((uint32_t)a->ff_run[r] << 24);
+			outp[s] = a->is_final_ref(r) ? a->head_of(r) : -1;
+			inb[s] = a->in_byte[r];
 		}
-		std::vector<uint8_t> inb(a->in_byte);
-		inb.resize((size_t)n + 32, 0);
-		std::vector<uint8_t> ffr(a->ff_run);
-		ffr.resize((size_t)n + 32, 0);
-
-		rc = upload(&d->d_cold, rows.data(), rows.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_ffinfo, ffinfo.data(), ffinfo.size(), &d->device_bytes);
-		if (rc == ACM_OK)
-			rc = upload(&d->d_ref2dev, a->ref2dev.data(), a->ref2dev.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_ff_run, ffr.data(), ffr.size(), &d->device_bytes);
-		if (rc == ACM_OK) {  // one image: T2 cells, then the filter bytes (LDS copy is one sweep)
-			std::vector<uint16_t> image(t2);
-			image.resize(t2.size() + bloom.size() / 2);
-			memcpy(image.data() + t2.size(), bloom.data(), bloom.size());
-			rc = upload(&d->d_t2, image.data(), image.size(), &d->device_bytes);
-			d->d_bloom = (uint8_t *)(d->d_t2 + t2.size());
+		{
+			std::vector<uint32_t> plane(rows.size());
+			for (size_t i = 0; i < rows.size(); i++)
+				plane[i] = (uint32_t)rows[i];
+			rc = upload(&d->d_cold, plane.data(), plane.size(), &d->device_bytes);
+			for (size_t i = 0; i < rows.size(); i++)
+				plane[i] = (uint32_t)(rows[i] >> 32);
+			if (rc == ACM_OK)
+				rc = upload(&d->d_meta, plane.data(), plane.size(), &d->device_bytes);
 		}
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_out, outp.data(), outp.size(), &d->device_bytes);
 		if (rc == ACM_OK)
 			rc = upload(&d->d_dev2ref, a->dev2ref.data(), a->dev2ref.size(), &d->device_bytes);
-		if (rc == ACM_OK)
-			rc = upload(&d->d_depth_cum, a->depth_cum.data(), a->depth_cum.size(),
-			    &d->device_bytes);
-		if (rc == ACM_OK)
-			rc = upload(&d->d_depth_final, dfin.data(), dfin.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
 	} catch (const std::bad_alloc &) {
 		rc = acm::fail(ACM_ERR_NOMEM, "acm_dfa_upload: out of host memory");
 	}
@@ -180,16 +129,11 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		return;
 	if (hipSetDevice(d->device) == hipSuccess) {
 		hipFree(d->d_cold);
+		hipFree(d->d_meta);
 		hipFree(d->d_hot);
 		hipFree(d->d_out);
 		hipFree(d->d_dev2ref);
-		hipFree(d->d_depth_cum);
-		hipFree(d->d_depth_final);
-		hipFree(d->d_ffinfo);
-		hipFree(d->d_ref2dev);
 		hipFree(d->d_in_byte);
-		hipFree(d->d_ff_run);
-		hipFree(d->d_t2);   // d_bloom points into the same allocation
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

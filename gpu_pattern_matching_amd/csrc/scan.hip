@@ -1,5 +1,5 @@
-// The scan pipeline: speculative chain walk -> boundary resolve -> exclusive
-// scan of per-chain counts -> ordered scatter.  gfx950 only.
+// The scan pipeline: speculative chain walk -> boundary resolve -> block scan
+// of per-chain counts -> ordered scatter.  gfx950 only.
 //
 // Replaces ahomatch.cl:1-165 (+ its launch, ocl_aho_match.c:96-131) and the
 // prefix-sum/compaction stage behind it (databuf.c:648-651), with the serial
@@ -10,30 +10,40 @@
 //
 //   The text is cut into chains of S bytes (S = 16..256, a power of two).
 //
-//   K1 spec_walk   every lane walks its chain(s) from the ROOT state.  The
-//                  state reached after m bytes equals the true serial state
-//                  as soon as the true state's depth is <= m (the state only
-//                  remembers its last depth bytes); from then on the two
-//                  walks coincide.  K1 records the end state e[j], the
-//                  tentative hits (staged per wave), their number and the
-//                  step of the first one.
-//   K2 resolve     lane j rebuilds the true state at its chain start from
-//                  e[] of the q = ceil(L/S) chains before it: continue from
-//                  e[j-q], and in every following chain walk only until the
-//                  depth test says the walk has merged with that chain's own
-//                  root walk, then jump to its e[].  Then it walks the head
-//                  of its own chain from the true state until the same test
-//                  holds; hits found there are staged separately.  If a K1
-//                  hit lies inside that unmerged head, K2 re-walks the whole
-//                  chain and K1's records for it are dropped.
-//                  Typical cost: a handful of steps per chain; worst case
-//                  (q-1)*S + S, the price of a classic (L-1)-byte halo.
-//   scan + scatter per-chain counts -> offsets -> records land in position
-//                  order; pattern index = out[state] is looked up here, off
-//                  the walk's critical path.
+//   K1 k_spec_walk   every lane walks its chains from the ROOT state.  The
+//                    state reached after m bytes equals the true serial state
+//                    as soon as the true state's depth is <= m (a state only
+//                    remembers its last depth bytes); from then on the two
+//                    walks coincide.  K1 records the end state e[j], the
+//                    tentative hits (staged per wave), their number and the
+//                    step of the first one.  Its tile epilogue already settles
+//                    the common case of the next two stages (see below).
+//   K2a k_probe      lane c walks chain c from e[c-1] -- the state chain c
+//                    starts in whenever chain c-1 has merged -- until the
+//                    depth test says it has merged with chain c's own root
+//                    walk: typically after one byte.
+//   K2b k_resolve    lane j: if every chain of its look-back window
+//                    (q = ceil(L/S) chains) merged in its probe, the true
+//                    start state is known without walking and K1's records
+//                    stand.  Otherwise it rebuilds the start state by walking
+//                    (re-using probe results wherever the walk enters a chain
+//                    in the state the probe assumed), re-walks the head of
+//                    its own chain from the true state, stages the true hits
+//                    and, if a K1 hit lies in the unmerged head, takes the
+//                    whole chain over (K1's records for it are dropped).
+//                    Worst case (q-1)*S + S steps: the price of a classic
+//                    (L-1)-byte halo, paid only where the text really is deep
+//                    inside a pattern.
+//   k_scan_top + k_scatter_all   per-chain counts -> offsets -> records land
+//                    in position order; pattern index = out[state] is looked
+//                    up here, off the walk's critical path.
 //
-// Depth test: non-final dev ids are in BFS order, so depth(s) <= m  <=>
-// s < depth_cum[m]; final states carry their depth in depth_final[].
+// Deep walks (K2) get everything about the state they enter with the state
+// itself: cold[idx] = state, meta[idx] = depth | run << 16 (same index, loaded
+// together).  depth feeds the merge
+// test; run is the length of the unary trie path ahead, along which states
+// are consecutive ids and the walk only compares text with in_byte[] --
+// 16 bytes per load level instead of one table lookup per byte.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -50,21 +60,15 @@ constexpr int kBlock1 = 1024;          // K1 workgroup: 16 waves, one per CU (LD
 constexpr int kWaves1 = kBlock1 / 64;
 constexpr int kBlock2 = 256;
 constexpr uint32_t kNoFirst = 0xFFFFu;
+constexpr uint8_t kProbeTodo = 0xFF;
 
 struct ScanArgs {
-	const uint32_t *cold;
+	const uint32_t *cold;   // [states][256] next state
+	const uint32_t *meta;   // [states][256] depth(next) | run(next) << 16
 	const uint16_t *hot;
 	const int32_t *out;
 	const uint32_t *dev2ref;
-	const uint32_t *depth_cum;
-	const uint16_t *depth_final;
-	const uint32_t *ffinfo;
-	const uint32_t *ref2dev;
 	const uint8_t *in_byte;
-	const uint8_t *ff_run;  // [ref + 32] unary run length from ref state r
-	const uint16_t *t2;     // bigram table image (root row + 65536 cells), see device_dfa.hip
-	const uint8_t *bloom;   // trigram filter image
-	uint32_t d2lo, d2hi;    // non-final depth-2 dev ids are [d2lo, d2hi)
 	const uint4 *text16;
 	const uint8_t *text;
 	uint32_t n;             // text bytes
@@ -73,6 +77,7 @@ struct ScanArgs {
 	uint32_t n_chains;
 	uint32_t n_tiles;       // K1 wave tiles
 	uint32_t H;             // hot rows
+	uint32_t hot_depth1;    // hot ids below this have depth <= 1
 	uint32_t F;             // first final dev id
 	uint32_t L;             // max pattern length
 	uint32_t q;             // look-back chains
@@ -80,16 +85,14 @@ struct ScanArgs {
 	uint32_t drop_before;   // records ending before this offset are context (halo), not output
 	int32_t off_shift;      // added to every reported offset
 	// workspace
-	uint32_t *end_state;
-	uint32_t *c1f;
-	uint32_t *k2info;
+	uint32_t *end_state;    // [chains] e[j]: end state of chain j's root walk
+	uint32_t *c1f;          // [chains] K1 hit count | first-hit step << 16
+	uint32_t *k2info;       // [chains] K2 hit count | K1 records dropped << 16
 	uint32_t *wend;         // [chains] end state of the probe walk of chain c from e[c-1]
-	uint8_t *probe;         // [chains] bit0: probe merged, bit1: chain needs an emission walk;
-	                        //          0xFF: not probed yet (k_probe does it)
-	uint8_t *rflag;         // [chains] 1: the walk kernel already resolved the chain (cnt, k2info set)
-	uint32_t cum1;          // depth_cum[1]: non-final ids below it have depth <= 1
-	int32_t *cnt;
-	int32_t *off;
+	uint8_t *probe;         // [chains] bit0 probe merged, bit1 head needs an emission walk
+	uint8_t *rflag;         // [chains] 1: resolved by the walk kernel's epilogue
+	int32_t *cnt;           // [chains] final record count of the chain
+	int32_t *off;           // [blocks] per-256-chain totals, scanned in place
 	uint32_t *wave_cnt1;
 	uint32_t *wave_cnt2;
 	uint32_t *misc;         // [0] last state (dev), [1] total records
@@ -106,6 +109,11 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
+__device__ __forceinline__ uint32_t cold_next(const ScanArgs &a, uint32_t idx)
+{
+	return a.cold[idx];
+}
+
 template <int K>
 __device__ __forceinline__ uint32_t byte_of(const uint4 &w)
 {
@@ -113,10 +121,16 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &w)
 	return (d >> (8 * (K & 3))) & 0xFFu;
 }
 
+// ---------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------
+
 // One DFA step for C independent chains, loads issued back to back so the
 // chains hide each other's latency.  Cold lanes (state beyond the LDS rows,
-// or an LDS cell that says "does not fit") read the HBM plane; the branch
-// around that is wave-uniform.
+// or an LDS cell that says "look in HBM") gather from the cold plane; the
+// branch around that is wave-uniform.  (Issuing the HBM gather before the LDS
+// result is known -- the plane a lane needs only depends on its state --
+// measured 35% SLOWER on MI355X, so the gather waits for the LDS cell.)
 template <int C, int K, bool GUARD>
 __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot, const uint4 (&w)[C],
     uint32_t (&st)[C], uint32_t (&cnt)[C], uint32_t (&first)[C], const uint32_t (&base)[C],
@@ -139,7 +153,7 @@ __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot,
 		uint32_t v[C];
 #pragma unroll
 		for (int c = 0; c < C; c++)
-			v[c] = a.cold[need[c] ? idx[c] : 0u];
+			v[c] = cold_next(a, need[c] ? idx[c] : 0u);
 #pragma unroll
 		for (int c = 0; c < C; c++)
 			e[c] = need[c] ? v[c] : e[c];
@@ -212,20 +226,22 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 				ok = true;
 			} else if (pe < a.H) {
 				const uint32_t t = hot[(pe << 8) | fb[c]];
-				ok = t < a.cum1;   // non-final, depth <= 1 (a sentinel cell is never < cum1)
+				ok = t < a.hot_depth1;   // non-final, depth <= 1 (a sentinel cell is never below)
 			}
 		}
 		decided[c] = ok;
 		dmask[c] = __builtin_amdgcn_ballot_w64(ok);
 	}
-	const uint32_t window = a.q - 1;   // chains before chain-1 that must have merged too
+	// chain j is settled when its own probe merged at step <= 1 and so did the
+	// probes of the q-1 chains before it (then the true start state is e[j-1])
+	const uint32_t window = a.q - 1;
 #pragma unroll
 	for (int c = 0; c < C; c++) {
 		if (chain[c] >= a.n_chains)
 			continue;
 		bool final_here = decided[c] && window <= 32;
 		const int p = c * 64 + (int)lane;   // position inside the tile
-		for (uint32_t k = 1; final_here && k <= window + 0u && k <= 32; k++) {
+		for (uint32_t k = 1; final_here && k <= window; k++) {
 			const int pos = p - (int)k;
 			if (pos < 0) {
 				final_here = (wt == 0);   // before the first chain of the text: nothing to check
@@ -237,10 +253,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 				mword = (pos >> 6) == cc ? dmask[cc] : mword;
 			final_here = (mword >> (pos & 63)) & 1ull;
 		}
-		// window counts the chains first..j-2; chain j-1 must have merged as well so that
-		// the true start state is e[j-1]: that is bit p-1, covered when window >= 1; for
-		// q == 1 the start state is e[j-1] by construction
-		a.probe[chain[c]] = decided[c] ? 1 : 0xFF;
+		a.probe[chain[c]] = decided[c] ? 1 : kProbeTodo;
 		if (decided[c])
 			a.wend[chain[c]] = st[c];
 		a.rflag[chain[c]] = final_here ? 1 : 0;
@@ -270,6 +283,8 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 	}
 	const uint32_t groups = a.S >> 4;
 	for (uint32_t g = 0; g < groups; g++) {
+		// (prefetching the next group does not help: vector loads return in order, so
+		// the first cold gather of this group would wait for the prefetch anyway)
 		uint4 w[C];
 #pragma unroll
 		for (int c = 0; c < C; c++) {
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
 	{
 		// every workgroup copies the same table: start each one at a different
-		// offset so the CUs do not all hit the same L2 channel at the same time
+		// offset so the CUs do not all ask the same L2 channel at the same time
 		const uint4 *src = (const uint4 *)a.hot;
 		uint4 *dst = (uint4 *)hot;
 		const uint32_t n16 = a.H * 32;  // 512 B per row
@@ -332,24 +347,9 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 	}
 }
 
-__device__ __forceinline__ bool depth_le(const ScanArgs &a, const uint32_t *cum, uint32_t s,
-    uint32_t m)
-{
-	if (s < a.F)
-		return s < cum[min(m, a.L + 1)];
-	return a.depth_final[s - a.F] <= m;
-}
-
-// depth_cum[] into LDS (dynamic, (L + 2) words) so the merge test costs no
-// global load on the walk's dependent chain
-__device__ __forceinline__ uint32_t *stage_depth_cum(const ScanArgs &a)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t cum_lds[];
-	for (uint32_t i = threadIdx.x; i < a.L + 2; i += blockDim.x)
-		cum_lds[i] = a.depth_cum[i];
-	__syncthreads();
-	return cum_lds;
-}
+// ---------------------------------------------------------------------------
+// K2: deep walks
+// ---------------------------------------------------------------------------
 
 // byte m-1 (m = 1-based step) of the text starting at 16-byte aligned 'base';
 // a 16-byte group is loaded when the walk enters it, off the dependent chain
@@ -374,258 +374,52 @@ struct ChainText {
 	}
 };
 
-// Fast-forward along a unary trie path.  'state' (dev id) was just entered;
-// text byte 'pos' is the next one to consume and at most 'limit' bytes may be
-// consumed.  While the text agrees with the single outgoing edge of each
-// state, the walk goes r -> r+1 -> ... in reference numbering, none of the
-// states entered is final, and depth grows in step with the bytes consumed
-// (so an unmerged walk stays unmerged).  Three dependent loads move the walk
-// up to 16 bytes; a table lookup per byte would need 16.
-__device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, uint32_t &state, uint32_t pos,
-    uint32_t limit)
+// the state a deep walk is in, with what the cell that produced it said
+struct Deep {
+	uint32_t s;       // dev id
+	uint32_t depth;   // trie depth of s
+	uint32_t run;     // unary, non-final trie path ahead: s+1, s+2, ... s+run
+};
+
+__device__ __forceinline__ Deep deep_step(const ScanArgs &a, uint32_t state, uint32_t byte)
 {
-	if (limit == 0 || pos + 16 > a.n_pad)
-		return 0;
-	const uint32_t info = a.ffinfo[state];
-	uint32_t run = info >> 24;
-	if (run == 0)
-		return 0;
-	uint32_t r = info & 0xFFFFFFu, total = 0;
-	// rounds of up to 16 bytes; after the first one everything a round needs
-	// (ff_run[r], in_byte[r+1..], text) hangs off r alone: one load level per round
-	for (;;) {
-		const uint32_t want = min(min(run, limit - total), 16u);
+	const size_t idx = ((size_t)state << 8) | byte;
+	const uint32_t next = a.cold[idx], m = a.meta[idx];   // two independent loads, one level
+	Deep d;
+	d.s = next;
+	d.depth = m & 0xFFFFu;
+	d.run = m >> 16;
+	return d;
+}
+
+// Fast-forward along the unary path ahead of d.  Text byte 'pos' is the next
+// one to consume, at most 'limit' bytes may be consumed.  While the text
+// agrees with the single outgoing edge of each state, the walk goes
+// s -> s+1 -> ...; none of the states entered is final and depth grows in
+// step with the bytes consumed (an unmerged walk stays unmerged).  One load
+// level moves the walk up to 16 bytes.  Returns the bytes consumed.
+__device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, Deep &d, uint32_t pos, uint32_t limit)
+{
+	uint32_t total = 0;
+	while (d.run != 0 && total < limit && pos + total + 16 <= a.n_pad) {
+		const uint32_t want = min(min(d.run, limit - total), 16u);
 		uint64_t e0, e1, t0, t1;
-		__builtin_memcpy(&e0, a.in_byte + r + 1, 8);
-		__builtin_memcpy(&e1, a.in_byte + r + 9, 8);
+		__builtin_memcpy(&e0, a.in_byte + d.s + 1, 8);
+		__builtin_memcpy(&e1, a.in_byte + d.s + 9, 8);
 		__builtin_memcpy(&t0, a.text + pos + total, 8);
 		__builtin_memcpy(&t1, a.text + pos + total + 8, 8);
-		const uint32_t run_next = a.ff_run[r + 16];   // used only after a full 16-byte round
 		const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
 		uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
 				   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
 		same = min(same, want);
-		r += same;
+		d.s += same;
+		d.depth += same;
+		d.run -= same;
 		total += same;
-		if (same < 16 || total >= limit || pos + total + 16 > a.n_pad)
-			break;
-		run = run_next;
-		if (run == 0)
-			break;
+		if (same < want || same < 16)
+			break;   // mismatch, or the run / the limit ended inside this round
 	}
-	if (total)
-		state = a.ref2dev[r];
 	return total;
-}
-
-// ---------------------------------------------------------------------------
-// K1, bigram form.  Same contract as k_spec_walk (exact root walk of every
-// chain: end state, staged hits, count, first-hit step) but the common step
-// has NO dependent load:
-//
-//   * LDS holds T2[prev byte][byte] = delta(delta(root, prev), byte): as long
-//     as the true state has depth <= 2, the state after a byte is a pure
-//     function of the last two text bytes, so the lookups of consecutive
-//     bytes are independent and pipeline freely.
-//   * The walk can only leave that regime by stepping from a depth-2 state
-//     to its depth-3 child.  That happens exactly when the last three bytes
-//     are a 3-byte pattern prefix; a trigram filter in LDS (also fed by text
-//     bytes only) flags the candidates.  Only candidates, lanes already deep,
-//     and cells that do not fit 16 bits touch the HBM plane.
-//   * Deep lanes fast-forward along unary trie paths and sit out the skipped
-//     steps, so a lane inside a long signature costs one gather per <= 16
-//     bytes instead of one per byte.
-// ---------------------------------------------------------------------------
-constexpr uint32_t kT2Cells = 256 + 65536;
-constexpr uint32_t kBloomBytes = 16384;                 // 128 Kbit
-constexpr uint32_t kBloomMul = 0x9E3779u;               // 24-bit odd multiplier
-constexpr size_t kBigramLds = kT2Cells * 2 + kBloomBytes;
-
-__device__ __forceinline__ uint32_t bloom_index(uint32_t trigram)
-{
-	return (__umul24(trigram, kBloomMul) >> 15) & (kBloomBytes * 8 - 1);
-}
-
-template <int C, int K, bool GUARD>
-__device__ __forceinline__ void bigram_step(const ScanArgs &a, const uint16_t *t2, const uint8_t *bloom,
-    const uint32_t (&carry)[C], const uint4 (&w)[C], uint32_t (&st)[C], uint32_t (&deep)[C],
-    uint32_t (&skip)[C], uint32_t (&cnt)[C], uint32_t (&first)[C], const uint32_t (&base)[C],
-    const uint32_t (&len)[C], uint32_t g, uint32_t &wcount, uint2 *stage)
-{
-	const uint32_t step = g * 16 + K + 1;   // 1-based; wave-uniform
-	uint32_t v[C], e[C], byte[C];
-	bool need[C], took[C];
-	bool any_need = false;
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		// v = text bytes (i-3, i-2, i-1, i), byte i in the top 8 bits
-		const uint32_t x[5] = { carry[c], w[c].x, w[c].y, w[c].z, w[c].w };
-		constexpr int lo = (K + 1) / 4, sh = (K + 1) % 4;
-		v[c] = sh == 0 ? x[lo] : __builtin_amdgcn_alignbyte(x[lo + 1], x[lo], sh);
-		byte[c] = v[c] >> 24;
-	}
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		const bool first_step = (step == 1);
-		e[c] = t2[first_step ? byte[c] : 256u + (v[c] >> 16)];
-	}
-	uint32_t bit[C];
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		const uint32_t h = bloom_index(v[c] >> 8);
-		bit[c] = (step >= 3) ? ((uint32_t)bloom[h >> 3] >> (h & 7)) & 1u : 0u;
-	}
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		const bool active = !GUARD || step <= len[c];
-		const bool is_d2 = (st[c] - a.d2lo) < (a.d2hi - a.d2lo);
-		const bool cand = (is_d2 && bit[c]) || (st[c] >= a.F && step >= 3);
-		const bool skipping = deep[c] && skip[c] > 0;
-		took[c] = active && !skipping;
-		need[c] = took[c] && (deep[c] || cand || e[c] == acm::kHotSentinel);
-		if (active && skipping)
-			skip[c]--;
-		any_need |= need[c];
-	}
-	if (__builtin_amdgcn_ballot_w64(any_need)) {
-		uint32_t t[C];
-#pragma unroll
-		for (int c = 0; c < C; c++)
-			t[c] = a.cold[need[c] ? ((st[c] << 8) | byte[c]) : 0u];
-#pragma unroll
-		for (int c = 0; c < C; c++) {
-			if (need[c]) {
-				// back in the bigram regime iff the exact state IS the table's value
-				const bool shallow = (t[c] == e[c]) && (e[c] != acm::kHotSentinel);
-				deep[c] = shallow ? 0u : 1u;
-				e[c] = t[c];
-				if (!shallow && t[c] < a.F) {
-					uint32_t s2 = t[c];
-					const uint32_t k = fast_forward(a, s2, base[c] + step, (GUARD ? len[c] : a.S) - step);
-					skip[c] = k;
-					e[c] = s2;           // state after the skipped bytes; none of them is final
-					// the hit test below sees a non-final state, as it must: t[c] < F and
-					// every state entered by the fast-forward is non-final
-				}
-			}
-		}
-	}
-	bool hit[C];
-	bool any_hit = false;
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		if (took[c])
-			st[c] = e[c];
-		hit[c] = took[c] && (e[c] >= a.F);
-		any_hit |= hit[c];
-	}
-	if (__builtin_amdgcn_ballot_w64(any_hit)) {
-#pragma unroll
-		for (int c = 0; c < C; c++) {
-			hit[c] = hit[c] && (base[c] + step - 1 >= a.drop_before);
-			const uint64_t m = __builtin_amdgcn_ballot_w64(hit[c]);
-			if (m) {
-				if (hit[c]) {
-					stage[wcount + mbcnt64(m)] =
-					    make_uint2(base[c] + step - 1, e[c] | (cnt[c] << 24));
-					if (cnt[c] == 0)
-						first[c] = step;
-					cnt[c]++;
-				}
-				wcount += (uint32_t)__popcll(m);
-			}
-		}
-	}
-}
-
-template <int C, bool GUARD>
-__device__ __forceinline__ void bigram_tile(const ScanArgs &a, const uint16_t *t2, const uint8_t *bloom,
-    uint32_t wt, uint32_t lane)
-{
-	uint32_t st[C], deep[C], skip[C], cnt[C], first[C], base[C], len[C], chain[C], carry[C];
-	uint32_t wcount = 0;
-	uint2 *stage = a.stage1 + (((size_t)wt * C * 64) << a.logS);
-	uint4 w[C];
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		chain[c] = (wt * C + c) * 64 + lane;
-		base[c] = chain[c] << a.logS;
-		len[c] = GUARD ? (base[c] >= a.n ? 0u : min(a.S, a.n - base[c])) : a.S;
-		st[c] = 0;
-		deep[c] = 0;
-		skip[c] = 0;
-		cnt[c] = 0;
-		first[c] = kNoFirst;
-		carry[c] = 0;
-		w[c] = (!GUARD || base[c] < a.n) ? a.text16[base[c] >> 4] : make_uint4(0, 0, 0, 0);
-	}
-	const uint32_t groups = a.S >> 4;
-	for (uint32_t g = 0; g < groups; g++) {
-		uint4 wn[C];
-#pragma unroll
-		for (int c = 0; c < C; c++) {  // next group in flight while this one is walked
-			if (g + 1 < groups && (!GUARD || base[c] + (g + 1) * 16 < a.n))
-				wn[c] = a.text16[(base[c] >> 4) + g + 1];
-			else
-				wn[c] = make_uint4(0, 0, 0, 0);
-		}
-#define ACM_BSTEP(K) \
-	bigram_step<C, K, GUARD>(a, t2, bloom, carry, w, st, deep, skip, cnt, first, base, len, g, wcount, stage)
-		ACM_BSTEP(0); ACM_BSTEP(1); ACM_BSTEP(2); ACM_BSTEP(3);
-		ACM_BSTEP(4); ACM_BSTEP(5); ACM_BSTEP(6); ACM_BSTEP(7);
-		ACM_BSTEP(8); ACM_BSTEP(9); ACM_BSTEP(10); ACM_BSTEP(11);
-		ACM_BSTEP(12); ACM_BSTEP(13); ACM_BSTEP(14); ACM_BSTEP(15);
-#undef ACM_BSTEP
-#pragma unroll
-		for (int c = 0; c < C; c++) {
-			carry[c] = w[c].w;
-			w[c] = wn[c];
-		}
-	}
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		if (chain[c] < a.n_chains) {
-			a.end_state[chain[c]] = st[c];
-			a.c1f[chain[c]] = cnt[c] | (first[c] << 16);
-			a.probe[chain[c]] = 0xFF;   // this variant leaves the whole resolve to K2
-			a.rflag[chain[c]] = 0;
-		}
-	}
-	if (lane == 0)
-		a.wave_cnt1[wt] = wcount;
-}
-
-template <int C>
-__global__ __launch_bounds__(kBlock1) void k_bigram_walk(ScanArgs a)
-{
-	extern __shared__ __attribute__((aligned(16))) uint16_t t2[];
-	uint8_t *bloom = (uint8_t *)(t2 + kT2Cells);
-	{
-		// T2 and the filter are contiguous in the image (device_dfa.hip).  Every
-		// workgroup copies the same bytes: start each one at a different offset so
-		// the CUs do not all hit the same L2 channel at the same time.
-		const uint4 *src = (const uint4 *)a.t2;
-		uint4 *dst = (uint4 *)t2;
-		constexpr uint32_t n16 = (uint32_t)(kBigramLds / 16);
-		const uint32_t rot = (blockIdx.x * 1021u) % n16;
-		for (uint32_t i = threadIdx.x; i < n16; i += kBlock1) {
-			uint32_t j = i + rot;
-			j = j >= n16 ? j - n16 : j;
-			dst[j] = src[j];
-		}
-	}
-	__syncthreads();
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = blockIdx.x * kWaves1 + (threadIdx.x >> 6);
-	const uint32_t nwaves = gridDim.x * kWaves1;
-	const uint32_t tile_bytes = (C * 64u) << a.logS;
-	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
-		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n;
-		if (full)
-			bigram_tile<C, false>(a, t2, bloom, wt, lane);
-		else
-			bigram_tile<C, true>(a, t2, bloom, wt, lane);
-	}
 }
 
 // K2a probe: lane c walks chain c from e[c-1] (the state chain c would start
@@ -634,49 +428,46 @@ __global__ __launch_bounds__(kBlock1) void k_bigram_walk(ScanArgs a)
 // whether it merged, the state at the end of the chain under that
 // assumption (wend), and whether anything in the unmerged head needs an
 // emission walk (a true hit there, or a K1 hit that must be dropped).
-// All lanes are independent: ~2 dependent loads in the common case.
+// Chains the walk kernel's epilogue already probed are skipped.
 __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 {
-	const uint32_t *cum = stage_depth_cum(a);
 	const uint32_t c = blockIdx.x * kBlock2 + threadIdx.x;
 	if (c >= a.n_chains)
 		return;
-	if (a.probe[c] != 0xFF)
-		return;   // the walk kernel already did this chain's probe in its epilogue
-	uint32_t s = c == 0 ? a.init_state : a.end_state[c - 1];
+	if (a.probe[c] != kProbeTodo)
+		return;
+	Deep d;
+	d.s = c == 0 ? a.init_state : a.end_state[c - 1];
+	d.depth = 0;
+	d.run = 0;
 	const uint32_t base = c << a.logS;
 	const uint32_t len = min(a.S, a.n - base);
 	const uint32_t f = a.c1f[c] >> 16;
-	bool merged = (s == 0), work = false;
+	bool merged = (d.s == 0), work = false;
 	if (!merged) {
 		ChainText txt(a, base);
 		for (uint32_t m = 1; m <= len; m++) {
-			s = a.cold[((size_t)s << 8) | txt.at(m)];
-			if (depth_le(a, cum, s, m)) {
+			d = deep_step(a, d.s, txt.at(m));
+			if (d.depth <= m) {
 				merged = true;
 				break;
 			}
-			work |= (s >= a.F) | (m >= f);
-			if (s >= a.H && s < a.F) {
-				m += fast_forward(a, s, base + m, len - m);
+			work |= (d.s >= a.F) | (m >= f);
+			if (d.run != 0 && d.s < a.F) {
+				m += fast_forward(a, d, base + m, len - m);
 				work |= (m >= f);
 			}
 		}
 	}
-	a.wend[c] = merged ? a.end_state[c] : s;
+	a.wend[c] = merged ? a.end_state[c] : d.s;
 	a.probe[c] = (uint8_t)((merged ? 1u : 0u) | (work ? 2u : 0u));
 }
 
-// K2b resolve: one lane per chain.  Fast path: every chain of the look-back
-// window merged in its probe, so the true start state is wend[j-1] and, when
-// that equals e[j-1], the probe of chain j IS the true walk of its head.
-// Otherwise the general algorithm runs for this lane: rebuild the start
-// state by walking, then walk the head of the own chain, staging hits.
+// K2b resolve: one lane per chain (see the file header).
 __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 {
 	__shared__ uint32_t wave_fill[kBlock2 / 64];
 	__shared__ uint32_t wave_sum[kBlock2 / 64];
-	const uint32_t *cum = stage_depth_cum(a);
 	const uint32_t j = blockIdx.x * kBlock2 + threadIdx.x;
 	const uint32_t wv = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 0)
@@ -713,28 +504,6 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 				// ---- general look-back: true state at the start of chain j ----
 				uint32_t c = first;
 				state = j < a.q ? a.init_state : a.end_state[j - a.q];
-				{
-					// Wherever the walk enters chain c in the state its probe assumed
-					// (e[c-1]), the probe's end state wend[c] is the answer.  Fetch the
-					// window's pairs with independent loads and consume them from
-					// registers, instead of a load-compare-load chain per chain.
-					constexpr uint32_t W = 8;
-					const uint32_t nwin = j - first;
-					uint32_t pe[W], pw[W];
-#pragma unroll
-					for (uint32_t i = 0; i < W; i++) {
-						const uint32_t cc = first + i;
-						const bool in = i < nwin && nwin <= W;
-						pe[i] = in ? (cc == 0 ? a.init_state : a.end_state[cc - 1]) : 0xFFFFFFFFu;
-						pw[i] = in ? a.wend[cc] : 0u;
-					}
-#pragma unroll
-					for (uint32_t i = 0; i < W; i++)
-						if (c == first + i && state == pe[i]) {
-							state = pw[i];
-							c++;
-						}
-				}
 				ChainText txt(a, first << a.logS);
 				while (c < j) {
 					if (m == 0 && state == 0) {  // root: merged with chain c's own walk
@@ -749,15 +518,16 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 					}
 					m++;
 					// chains are adjacent: step m of chain c is byte (c - first) * S + m - 1
-					state = a.cold[((size_t)state << 8) | txt.at(((c - first) << a.logS) + m)];
-					if (depth_le(a, cum, state, m)) {
+					Deep d = deep_step(a, state, txt.at(((c - first) << a.logS) + m));
+					if (d.depth <= m) {
 						state = a.end_state[c];
 						c++;
 						m = 0;
 						continue;
 					}
-					if (state >= a.H && state < a.F)
-						m += fast_forward(a, state, (c << a.logS) + m, a.S - m);
+					if (d.run != 0 && d.s < a.F)
+						m += fast_forward(a, d, (c << a.logS) + m, a.S - m);
+					state = d.s;
 					if (m == a.S) {
 						c++;
 						m = 0;
@@ -772,8 +542,9 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 			if (!merged) {
 				ChainText txt(a, base);
 				for (m = 1; m <= len; m++) {
-					state = a.cold[((size_t)state << 8) | txt.at(m)];
-					if (!killed && depth_le(a, cum, state, m)) {
+					Deep d = deep_step(a, state, txt.at(m));
+					state = d.s;
+					if (!killed && d.depth <= m) {
 						merged = true;
 						break;
 					}
@@ -784,8 +555,9 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 					}
 					if (!killed && m >= f)
 						killed = true;  // a K1 hit sits in the unmerged head: take the chain over
-					if (state >= a.H && state < a.F) {
-						m += fast_forward(a, state, base + m, len - m);
+					if (d.run != 0 && state < a.F) {
+						m += fast_forward(a, d, base + m, len - m);
+						state = d.s;
 						if (!killed && m >= f)
 							killed = true;
 					}
@@ -815,6 +587,10 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 		a.off[blockIdx.x] = (int32_t)t;
 	}
 }
+
+// ---------------------------------------------------------------------------
+// scan of the block totals + ordered scatter
+// ---------------------------------------------------------------------------
 
 // exclusive scan, in place, of the per-block totals by ONE workgroup: each
 // thread owns a contiguous slice, the 1024 slice sums go through a Blelloch
@@ -933,28 +709,27 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 	}
 }
 
-// header and trailer cells of the compact planes (compactarray.cl:49-55)
-__global__ void k_finalize(ScanArgs a, int have_chains)
+// empty text: header and trailer only
+__global__ void k_finalize_empty(ScanArgs a)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0)
 		return;
-	const uint32_t total = have_chains ? a.misc[1] : 0u;
-	const uint32_t last = have_chains ? a.misc[0] : a.init_state;
-	const int32_t last_ref = (int32_t)a.dev2ref[last];
-	uint32_t tail = total + 1;
-	if (tail > a.plane_capacity - 1)
-		tail = a.plane_capacity - 1;
-	a.pat_plane[0] = (int32_t)total;
-	a.off_plane[0] = (int32_t)total;
-	a.pat_plane[tail] = last_ref;
-	a.off_plane[tail] = last_ref;
+	const int32_t last_ref = (int32_t)a.dev2ref[a.init_state];
+	a.pat_plane[0] = 0;
+	a.off_plane[0] = 0;
+	a.pat_plane[1] = last_ref;
+	a.off_plane[1] = last_ref;
 }
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-	size_t end_state, c1f, k2info, wend, probe, rflag, cnt, off, wave_cnt1, wave_cnt2, misc, stage1, stage2,
-	    scan_ws;
+	size_t end_state, c1f, k2info, wend, probe, rflag, cnt, off, wave_cnt1, wave_cnt2, misc, stage1,
+	    stage2, scan_ws;
 	size_t scan_ws_bytes;
 	size_t total;
 };
@@ -985,23 +760,10 @@ Layout layout_for(size_t max_text)
 	l.misc = take(64);
 	l.stage1 = take(stage_recs * 8);
 	l.stage2 = take(stage_recs * 8);
-	l.scan_ws_bytes = acm_exclusive_scan_workspace_bytes(chains);
+	l.scan_ws_bytes = acm_exclusive_scan_workspace_bytes(chains / kBlock2 + 2);
 	l.scan_ws = take(l.scan_ws_bytes);
 	l.total = o;
 	return l;
-}
-
-template <int C>
-int launch_bigram_walk(const ScanArgs &a, int num_cus, hipStream_t s)
-{
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_bigram_walk<C>,
-	    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigramLds));
-	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
-	if (blocks > (uint32_t)num_cus)
-		blocks = (uint32_t)num_cus;
-	hipLaunchKernelGGL(k_bigram_walk<C>, dim3(blocks), dim3(kBlock1), kBigramLds, s, a);
-	ACM_HIP_TRY(hipGetLastError());
-	return ACM_OK;
 }
 
 template <int C>
@@ -1036,8 +798,6 @@ extern "C" int acm_scan_set_chain_bytes(acm_dfa *d, int chain_bytes)
 	return d->chain_bytes;
 }
 
-extern "C" int acm_scan_kernel_count(void) { return 5; }
-
 extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 {
 	if (!d)
@@ -1047,16 +807,7 @@ extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 	return d->chains_per_lane;
 }
 
-extern "C" int acm_scan_set_walk_variant(acm_dfa *d, int variant)
-{
-	if (!d)
-		return -1;
-	if (variant == 0 || variant == 1)
-		d->use_bigram = variant == 1;
-	else if (variant == -1)
-		d->use_bigram = d->bigram_default;
-	return d->use_bigram ? 1 : 0;
-}
+extern "C" int acm_scan_kernel_count(void) { return 5; }
 
 extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, long init_state,
     void *d_workspace, size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
@@ -1092,7 +843,7 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 
 	// geometry: enough chains to give every lane of every CU work, chains
 	// as long as that allows (longer chains = fewer look-back steps)
-	const int C = d->chains_per_lane == 4 ? 4 : 2;   // chains a lane interleaves in the walk kernel
+	const int C = d->chains_per_lane == 2 ? 2 : 4;
 	uint32_t S = (uint32_t)d->chain_bytes;
 	if (S == 0) {
 		const size_t lanes = (size_t)d->num_cus * kBlock1 * C;
@@ -1108,19 +859,11 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	ScanArgs a;
 	memset(&a, 0, sizeof(a));
 	a.cold = d->d_cold;
+	a.meta = d->d_meta;
 	a.hot = d->d_hot;
 	a.out = d->d_out;
 	a.dev2ref = d->d_dev2ref;
-	a.depth_cum = d->d_depth_cum;
-	a.depth_final = d->d_depth_final;
-	a.ffinfo = d->d_ffinfo;
-	a.ref2dev = d->d_ref2dev;
 	a.in_byte = d->d_in_byte;
-	a.ff_run = d->d_ff_run;
-	a.t2 = d->d_t2;
-	a.bloom = d->d_bloom;
-	a.d2lo = d->d2lo;
-	a.d2hi = d->d2hi;
 	a.text16 = (const uint4 *)d_text;
 	a.text = (const uint8_t *)d_text;
 	a.n = (uint32_t)n;
@@ -1130,6 +873,7 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.n_chains = (uint32_t)((n + S - 1) >> logS);
 	a.n_tiles = (a.n_chains + C * 64 - 1) / (C * 64);
 	a.H = d->hot_rows;
+	a.hot_depth1 = d->hot_depth1;
 	a.F = d->first_final;
 	a.L = d->max_pattern_len;
 	a.q = (a.L + S - 1) / S;
@@ -1144,7 +888,6 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.wend = (uint32_t *)(ws + l.wend);
 	a.probe = (uint8_t *)(ws + l.probe);
 	a.rflag = (uint8_t *)(ws + l.rflag);
-	a.cum1 = d->cum1;
 	a.cnt = (int32_t *)(ws + l.cnt);
 	a.off = (int32_t *)(ws + l.off);
 	a.wave_cnt1 = (uint32_t *)(ws + l.wave_cnt1);
@@ -1157,7 +900,7 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	a.plane_capacity = (uint32_t)plane_capacity;
 
 	if (a.n_chains == 0) {
-		hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, a, 0);
+		hipLaunchKernelGGL(k_finalize_empty, dim3(1), dim3(64), 0, s, a);
 		ACM_HIP_TRY(hipGetLastError());
 		return ACM_OK;
 	}
@@ -1174,20 +917,15 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 		}
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	}
-	int rc;
-	if (C == 4)
-		rc = d->use_bigram ? launch_bigram_walk<4>(a, d->num_cus, s) : launch_spec_walk<4>(a, d->num_cus, s);
-	else
-		rc = d->use_bigram ? launch_bigram_walk<2>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
+	int rc = C == 4 ? launch_spec_walk<4>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
 	if (rc != ACM_OK)
 		return rc;
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
-	const size_t cum_lds = ((size_t)a.L + 2) * sizeof(uint32_t);
-	hipLaunchKernelGGL(k_probe, dim3((a.n_chains + kBlock2 - 1) / kBlock2), dim3(kBlock2), cum_lds, s, a);
-	hipLaunchKernelGGL(k_resolve, dim3((a.n_chains + kBlock2 - 1) / kBlock2), dim3(kBlock2), cum_lds, s, a);
+	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2 blocks == scatter blocks
+	hipLaunchKernelGGL(k_probe, dim3(nb), dim3(kBlock2), 0, s, a);
+	hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
-	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2b blocks == scatter blocks
 	if (nb <= kTopMax) {
 		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kTopThreads), 0, s, a, nb);
 	} else {  // > 16M chains: generic multi-level scan of the block totals

@@ -164,11 +164,6 @@ int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
  * Returns the value in use. */
 int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
 
-/* walk kernel variant: 0 = BFS hot rows in LDS (k_spec_walk), 1 = bigram
- * table + trigram filter in LDS (k_bigram_walk), -1 = the automatic choice
- * made at upload.  Returns the variant in use.  Results are identical. */
-int acm_scan_set_walk_variant(acm_dfa *, int variant);
-
 /* number of kernels one acm_scan_async enqueues for a non-empty text */
 int acm_scan_kernel_count(void);
 

@@ -34,7 +34,6 @@ def matcher_for(name, max_text=1 << 20):
     m = _matchers[name]
     m.reserve(max_text)
     m.set_chain_bytes(0)
-    m.set_walk_variant(-1)
     m.set_chains_per_lane(4)
     return m
 
@@ -66,12 +65,11 @@ def test_golden_vectors(gpu, name, idx):
     assert (np.diff(pos.astype(np.int64)) > 0).all()      # strictly increasing offsets
 
 
-@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("chain", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("name", ["tests", "sentiment", "clamav2000", "clamav2000_m12"])
-def test_chain_length_invariance(gpu, name, chain, variant):
-    """The result must not depend on how the text is cut into chains, nor on the walk kernel
-    (0 = BFS hot rows in LDS, 1 = bigram table + trigram filter in LDS)."""
+def test_chain_length_invariance(gpu, name, chain):
+    """The result must not depend on how the text is cut into chains, nor on how many chains a
+    lane interleaves in the walk kernel."""
     o = fixtures.oracle_for(name)
     pats = fixtures.patterns_of(name)
     if name == "sentiment":
@@ -80,26 +78,10 @@ def test_chain_length_invariance(gpu, name, chain, variant):
         text = fixtures.text_for({"kind": "clamav", "n": 300001, "seed": 4, "n_plant": 300}, pats)
     m = matcher_for(name)
     m.set_chain_bytes(chain)
-    assert m.set_walk_variant(variant) == variant
     exp = o.scan(text)
     for cpl in (2, 4):
         assert m.set_chains_per_lane(cpl) == cpl
         assert_same(m.scan(text), exp)
-
-
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("name,idx", [("clamav2000", 1), ("clamav15000", 1), ("sentiment", 1),
-                                      ("clamav2000", 2)])
-def test_golden_both_walk_variants(gpu, name, idx, variant):
-    spec = GOLDEN[name]["texts"][idx]
-    pats = fixtures.patterns_of(name) if spec["kind"] in ("clamav", "repeat") else None
-    text = fixtures.text_for(spec, pats)
-    m = matcher_for(name, max_text=max(text.size, 1 << 20))
-    m.set_walk_variant(variant)
-    pos, pat, last = m.scan(text)
-    assert pos.size == spec["count"]
-    assert "%016x" % orc.records_digest(pos, pat) == spec["records_digest"]
-    assert last == spec["final_state"]
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 4095, 4096, 4097, 8191,
@@ -109,8 +91,8 @@ def test_ragged_lengths(gpu, n):
     base = np.fromfile(os.path.join(orc.DATA, "ref_tests", "input.txt"), dtype=np.uint8)
     text = np.tile(base, 8)[:n]
     m = matcher_for("tests")
-    for variant in (0, 1):
-        m.set_walk_variant(variant)
+    for cpl in (2, 4):
+        m.set_chains_per_lane(cpl)
         for chain in (16, 64):
             m.set_chain_bytes(chain)
             assert_same(m.scan(text), o.scan(text))
@@ -149,8 +131,8 @@ def test_deep_states_everywhere(gpu):
     for pid in (5, longest):
         p = pats[pid]
         text = np.frombuffer((p * (200000 // len(p) + 1))[:200000], dtype=np.uint8)
-        for variant in (0, 1):
-            m.set_walk_variant(variant)
+        for cpl in (2, 4):
+            m.set_chains_per_lane(cpl)
             for chain in (16, 64, 256):
                 m.set_chain_bytes(chain)
                 assert_same(m.scan(text), o.scan(text))
@@ -168,8 +150,8 @@ def test_every_position_matches(gpu):
     o.compile()
     text = np.full(100000, ord("a"), dtype=np.uint8)
     m = Matcher(a, 0, max_text=text.size)
-    for variant in (0, 1):
-        m.set_walk_variant(variant)
+    for cpl in (2, 4):
+        m.set_chains_per_lane(cpl)
         for chain in (16, 256):
             m.set_chain_bytes(chain)
             got = m.scan(text)
