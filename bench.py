@@ -162,6 +162,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     walk_ms, pipe_ms, launches = matcher.profile_read()
+    # the same kernels with ONE batch in flight (outside the timed region): how long the walk
+    # takes when it has the GPU to itself, for reading the roofline beside the shared figure
+    solo_walk_ms = solo_pipe_ms = 0.0
+    solo_n = 0
+    if W > 1:
+        for k in range(0, 10 * W, W):
+            step(k)
+            drain()
+            torch.cuda.synchronize()
+        solo_walk_ms, solo_pipe_ms, solo_n = matcher.profile_read()
     matcher.profile(False)
 
     if world > 1:
@@ -276,8 +286,19 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": round(walk_s * 1e6, 2),
                 "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
+                "note": "HIP events on each batch's own stream inside the timed region; with %d batches "
+                        "in flight the walk shares the GPU with the other batch's kernels" % W,
             },
         }
+        if solo_n:
+            sw = solo_walk_ms / 1e3 / solo_n
+            out["roofline_one_batch_in_flight"] = {
+                "kernel_us": round(sw * 1e6, 2),
+                "pipeline_us": round(solo_pipe_ms / solo_n * 1e3, 2),
+                "achieved": round(alg_bytes / sw / 1e9, 2),
+                "frac": round(alg_bytes / sw / 1e9 / HBM_PEAK_GBS, 5),
+                "launches": solo_n,
+            }
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

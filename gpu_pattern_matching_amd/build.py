@@ -15,6 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libacmatch.so")
+CLI = os.path.join(PKG, "acm_grep")          # native CLI (csrc/acm_grep.cpp), host code only
 
 SOURCES = ["automaton.cpp", "device_dfa.hip", "scan.hip", "post.hip", "runtime.hip", "compat.hip"]
 ARCH = "gfx950"
@@ -43,8 +44,7 @@ def _stale(target, deps):
 
 def build(force=False, keep_temps=False, verbose=False):
     """Compile every translation unit and link libacmatch.so. Returns its path."""
-    sources = [os.path.join(CSRC, f) for f in SOURCES]
-    if not force and not keep_temps and not _stale(LIB, _deps()):
+    if not force and not keep_temps and not _stale(LIB, _deps()) and not _stale(CLI, _deps() + [LIB]):
         return LIB          # up to date (object files are scratch and need not exist)
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
@@ -65,6 +65,13 @@ def build(force=False, keep_temps=False, verbose=False):
             subprocess.check_call(cmd, cwd=OBJ)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or _stale(CLI, [os.path.join(CSRC, "acm_grep.cpp"), os.path.join(ROOT, "include", "acmatch.h"), LIB]):
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+               os.path.join(CSRC, "acm_grep.cpp"), "-o", CLI, "-L" + PKG, "-lacmatch", "-lpthread",
+               "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

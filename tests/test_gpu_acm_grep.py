@@ -1,0 +1,102 @@
+"""acm_grep, the native CLI: flags, -v line format, STATS block, rounds with a
+carried state, directory input, several workers, text mode -- against the oracle, and against the
+reference's own CLI binary (built from its sources against libacmatch.so) where that exists."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import fixtures
+import orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gpu_pattern_matching_amd", "acm_grep")
+REF_CLI = os.path.join(orc.ORACLE_DIR, "_ref", "ocl_aho_grep_acm")
+LINE = re.compile(r"^Pattern (-?\d+) \('(.*)'\) found in file '(.*)' at offset (\d+) \[relative: (-?\d+)\]$")
+
+
+def run(binary, args):
+    p = subprocess.run([binary] + args, capture_output=True, text=True, timeout=180, errors="replace")
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    hits = [m.groups() for m in (LINE.match(l) for l in p.stdout.splitlines()) if m]
+    stats = dict(re.findall(r"^([A-Za-z ()]+):\s+([\d.]+)$", p.stdout, flags=re.M))
+    return hits, stats, p.stdout
+
+
+def test_fixture_matches_oracle_and_reference_cli(gpu):
+    text_path = os.path.join(orc.DATA, "ref_tests", "input.txt")
+    pat_path = os.path.join(orc.DATA, "ref_tests", "patterns.txt")
+    args = ["-f", text_path, "-p", pat_path, "-B", "2048", "-D", "0", "-G", "8", "-L", "1024", "-w", "1", "-v"]
+    hits, stats, out = run(CLI, args)
+    o = fixtures.oracle_for("tests")
+    pos, pat, _ = o.scan(np.fromfile(text_path, dtype=np.uint8))
+    assert int(stats["Matches"]) == int(stats["Matches reported"]) == pos.size == 24
+    assert int(stats["Automaton states"]) == 198
+    assert int(stats["Processed bytes"]) == 9479 and int(stats["Kernel launches"]) == 1
+    want = [(str(o.pattern(k)[1]), o.pattern(k)[0].decode(), text_path, str(p + 1), str(p + 1 - p // 2048 * 2048))
+            for p, k in zip(pos.tolist(), pat.tolist())]
+    assert hits == want
+    if os.path.exists(REF_CLI):      # the reference's own tool, same flags: identical match lines
+        ref_hits, ref_stats, _ = run(REF_CLI, args)
+        assert ref_hits == hits
+        for key in ("Matches", "Matches reported", "Automaton states", "Processed bytes", "Kernel launches"):
+            assert ref_stats[key] == stats[key]
+
+
+def test_directory_workers_and_rounds(gpu, tmp_path):
+    """A directory of files, two workers, buffers smaller than the files: every file's matches are
+    found, whichever worker and round they fall into (state carried per worker)."""
+    name = "clamav2000_m12"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    d = tmp_path / "inputs"
+    d.mkdir()
+    total, per_file = 0, {}
+    for i in range(5):
+        t = fixtures.text_for({"kind": "clamav", "n": 300000 + 1111 * i, "seed": 40 + i, "n_plant": 120}, pats)
+        (d / ("f%d.bin" % i)).write_bytes(t.tobytes())
+        per_file[str(d / ("f%d.bin" % i))] = t
+        total += t.size
+    sigs = orc.clamav_file(2000, str(tmp_path))
+    hits, stats, out = run(CLI, ["-f", str(d), "-p", sigs, "-x", "-m", "12", "-B", "4096", "-D", "0", "-G", "32",
+                                 "-L", "1024", "-w", "2", "-v"])
+    assert int(stats["Processed files"]) == 5 and int(stats["Processed bytes"]) == total
+    # a worker scans its files as ONE stream (the reference carries last_state across files too,
+    # databuf.c:622): count per worker stream = serial scan of the concatenation in readdir order
+    order = [os.path.join(str(d), e) for e in os.listdir(str(d))]
+    # acm_grep walks the directory with readdir(), the same order os.listdir reports on this fs
+    expect = 0
+    for w in range(2):
+        stream = np.concatenate([per_file[f] for f in order[w::2]])
+        expect += o.scan(stream)[0].size
+    assert int(stats["Matches"]) == expect
+    assert int(stats["Matches reported"]) == expect
+    assert int(stats["Kernel launches"]) >= total // (32 * 4096)
+
+
+def test_text_mode(gpu, tmp_path):
+    o = fixtures.oracle_for("sentiment")
+    text = fixtures.text_for({"kind": "words", "n": 200000, "seed": 9}, None).tobytes()
+    lines, pos, rng = [], 0, np.random.default_rng(9)
+    while pos < len(text):
+        ln = int(rng.integers(10, 100))
+        lines.append(text[pos:pos + ln].replace(b"\n", b" ") + b"\n")
+        pos += ln
+    f = tmp_path / "lines.txt"
+    f.write_bytes(b"".join(lines))
+    pat_path = os.path.join(orc.DATA, "sentiment", "patterns_categorical.txt")
+    hits, stats, out = run(CLI, ["-f", str(f), "-p", pat_path, "-t", "-B", "256", "-D", "0", "-G", "1024",
+                                 "-L", "1024", "-w", "1", "-R", "64"])
+    stream = np.frombuffer(b"".join(lines), dtype=np.uint8)
+    assert int(stats["Matches"]) == o.scan(stream)[0].size
+    assert int(stats["Processed lines"]) == len(lines)
+    assert int(stats["Processed bytes"]) == stream.size
+
+
+def test_usage_errors(gpu):
+    p = subprocess.run([CLI, "-f", "x"], capture_output=True, text=True)
+    assert p.returncode != 0 and "No pattern file" in p.stdout
