@@ -122,6 +122,8 @@ struct Shared {
 	std::vector<std::string> pat_bytes;   // for the -v line
 	std::vector<int> pat_iid;
 	pthread_mutex_t print_lock = PTHREAD_MUTEX_INITIALIZER;
+	pthread_barrier_t ready;   // workers have their buffers; the clock starts (the reference
+	                           // also allocates in ocl_worker_ctx_init, before start_time)
 };
 
 struct Buffer {   // one of the two staging buffers of a worker
@@ -317,6 +319,7 @@ void *worker_main(void *arg)
 	CK(acm_rt_malloc(&w.ws, w.ws_bytes));
 	buffer_alloc(w.buf[0], c);
 	buffer_alloc(w.buf[1], c);
+	pthread_barrier_wait(&sh.ready);
 
 	const int nfiles = (int)sh.files.size();
 	int cur = w.id, filling = 0;
@@ -483,7 +486,7 @@ int main(int argc, char **argv)
 
 	signal(SIGINT, on_sigint);
 	std::vector<Worker> workers((size_t)c.threads);
-	const double t0 = now_us();
+	pthread_barrier_init(&sh.ready, nullptr, (unsigned)c.threads + 1);
 	for (int i = 0; i < c.threads; i++) {
 		workers[i].sh = &sh;
 		workers[i].id = i;
@@ -492,6 +495,8 @@ int main(int argc, char **argv)
 			return 1;
 		}
 	}
+	pthread_barrier_wait(&sh.ready);
+	const double t0 = now_us();
 	size_t matches = 0, reported = 0, bytes = 0, lines = 0, rounds = 0;
 	for (auto &w : workers) {
 		pthread_join(w.thread, nullptr);
