@@ -64,10 +64,18 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # rehearsal mode for a one-GPU box: ACM_BENCH_BACKEND=gloo puts every rank on cuda:0 and
+    # moves the gather through host memory; the real multi-GPU run uses RCCL ("nccl")
+    backend = os.environ.get("ACM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import synth  # tests/synth.py: seeded corpus
     from gpu_pattern_matching_amd import Automaton, Matcher, build, sharding
@@ -126,22 +134,32 @@ def main():
     def step(k):
         wk = workers[k % W]
         buf = (k // W) & 1
-        if wk.pending[buf] is not None:             # the gather that last used this buffer
-            wk.pending[buf].wait()
+        if wk.pending[buf] is not None:             # the gather that last used this buffer:
+            with torch.cuda.stream(wk.stream):      # the worker's stream waits for it, not the host
+                wk.pending[buf].wait()
             wk.pending[buf] = None
         p = wk.planes[buf]
         matcher.scan_async(d_text, n_local, 0, wk.stream.cuda_stream, p[0], p[1], cap, halo=plan["halo"],
                            offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes))
-        if world > 1:
+        if world > 1 and backend == "nccl":
             with torch.cuda.stream(wk.stream):
                 wk.pending[buf] = dist.gather(p, gather_list=wk.gathered[buf] if rank == 0 else None,
                                               dst=0, async_op=True)
+        elif world > 1:   # rehearsal: through the host
+            wk.stream.synchronize()
+            host = p.cpu()
+            bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, gather_list=bufs, dst=0)
+            if rank == 0:
+                for g, h in zip(wk.gathered[buf], bufs):
+                    g.copy_(h)
 
     def drain():
         for wk in workers:
             for b in (0, 1):
                 if wk.pending[b] is not None:
-                    wk.pending[b].wait()
+                    with torch.cuda.stream(wk.stream):
+                        wk.pending[b].wait()
                     wk.pending[b] = None
 
     def fence():
@@ -174,8 +192,9 @@ def main():
         solo_walk_ms, solo_pipe_ms, solo_n = matcher.profile_read()
     matcher.profile(False)
 
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -186,7 +205,7 @@ def main():
     m_local = int(local[0, 0])
     m_total = m_local
     if world > 1:
-        t = torch.tensor([m_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([m_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t)
         m_total = int(t.item())
 
