@@ -18,6 +18,7 @@ Weak scaling: 32 MiB per GPU.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -48,6 +49,9 @@ def main():
     ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=2, help="batches in flight (HIP streams)")
+    ap.add_argument("--chain-walks", action="store_true",
+                    help="chain the walk kernels of consecutive batches with events (acm_scan_batch_async); "
+                         "measured slower than letting the streams run free on MI355X")
     ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,6 +83,7 @@ def main():
 
     import synth  # tests/synth.py: seeded corpus
     from gpu_pattern_matching_amd import Automaton, Matcher, build, sharding
+    from gpu_pattern_matching_amd._lib import check
     build.build()          # no-op when libacmatch.so is current; raises if it cannot be built
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
@@ -129,6 +134,14 @@ def main():
                              for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
 
     workers = [Worker() for _ in range(W)]
+    # the walk kernels of consecutive batches are chained by events (batch k+1's walk starts when
+    # batch k's walk is done): only the walks serialise, everything behind them overlaps
+    walk_done = []
+    for _ in range(2 * W):
+        e = C.c_void_p()
+        check(matcher.lib.acm_rt_event_create(C.byref(e)), "acm_rt_event_create")
+        walk_done.append(e)
+    issued = [0]
     torch.cuda.synchronize()
 
     def step(k):
@@ -139,8 +152,14 @@ def main():
                 wk.pending[buf].wait()
             wk.pending[buf] = None
         p = wk.planes[buf]
+        i = issued[0]
+        issued[0] += 1
+        chain = args.chain_walks and W > 1
+        wait = walk_done[(i - 1) % len(walk_done)] if (chain and i > 0) else None
         matcher.scan_async(d_text, n_local, 0, wk.stream.cuda_stream, p[0], p[1], cap, halo=plan["halo"],
-                           offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes))
+                           offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes),
+                           wait_before_walk=wait,
+                           record_after_walk=walk_done[i % len(walk_done)] if chain else None)
         if world > 1 and backend == "nccl":
             with torch.cuda.stream(wk.stream):
                 wk.pending[buf] = dist.gather(p, gather_list=wk.gathered[buf] if rank == 0 else None,

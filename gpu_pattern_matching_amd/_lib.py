@@ -18,6 +18,14 @@ _i32p = C.POINTER(C.c_int32)
 _u32p = C.POINTER(C.c_uint32)
 
 
+class ScanBatch(C.Structure):
+    """struct acm_scan_batch (include/acmatch.h)."""
+    _fields_ = [("d_text", _vp), ("n", C.c_size_t), ("halo", C.c_size_t), ("offset_shift", C.c_long),
+                ("init_state", C.c_long), ("d_workspace", _vp), ("workspace_bytes", C.c_size_t),
+                ("d_pat_plane", _vp), ("d_off_plane", _vp), ("plane_capacity", C.c_size_t),
+                ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp)]
+
+
 class AcmError(RuntimeError):
     def __init__(self, code, where, detail):
         super().__init__("%s: %s (code %d)" % (where, detail, code))
@@ -53,6 +61,7 @@ NATIVE_API = {
                                  C.c_size_t, _vp]),
     "acm_scan_shard_async": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_long, C.c_long, _vp,
                                        C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "acm_scan_batch_async": (C.c_int, [_vp, C.POINTER(ScanBatch)]),
     "acm_scan_set_chain_bytes": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_chains_per_lane": (C.c_int, [_vp, C.c_int]),
     "acm_scan_kernel_count": (C.c_int, []),

@@ -176,12 +176,25 @@ class Matcher:
         return self.lib.acm_scan_set_chains_per_lane(self.dfa, c)
 
     def scan_async(self, d_text, n, init_state=0, stream=None, pat_plane=None, off_plane=None,
-                   plane_capacity=None, halo=0, offset_shift=0, workspace=None):
+                   plane_capacity=None, halo=0, offset_shift=0, workspace=None, wait_before_walk=None,
+                   record_after_walk=None):
         """Enqueue one scan of device text; nothing is synchronised.
 
         halo/offset_shift: shard form (acm_scan_shard_async).  workspace: (ptr, nbytes) of a
-        caller-owned scratch block instead of the matcher's own.
+        caller-owned scratch block instead of the matcher's own.  wait_before_walk /
+        record_after_walk: hipEvent_t handles chaining the walk kernels of batches that are in
+        flight on different streams (acm_scan_batch_async).
         """
+        if wait_before_walk is not None or record_after_walk is not None:
+            st = stream if stream is not None else self.stream
+            ws_ptr, ws_bytes = workspace if workspace is not None else (self.ws.ptr, self.ws_bytes)
+            b = _lib.ScanBatch(_ptr(d_text), n, halo, offset_shift, init_state, _ptr(ws_ptr), ws_bytes,
+                               _ptr(pat_plane) if pat_plane is not None else self.pat_plane.ptr,
+                               _ptr(off_plane) if off_plane is not None else self.off_plane.ptr,
+                               plane_capacity if plane_capacity is not None else self.plane_capacity,
+                               st, wait_before_walk, record_after_walk)
+            check(self.lib.acm_scan_batch_async(self.dfa, C.byref(b)), "acm_scan_batch_async")
+            return
         if workspace is None and n > self.max_text:
             raise ValueError("text of %d bytes exceeds reserved %d" % (n, self.max_text))
         st = stream if stream is not None else self.stream

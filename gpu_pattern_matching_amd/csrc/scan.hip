@@ -821,6 +821,34 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
     long offset_shift, long init_state, void *d_workspace, size_t workspace_bytes,
     int32_t *d_pat_plane, int32_t *d_off_plane, size_t plane_capacity, void *stream)
 {
+	acm_scan_batch b;
+	memset(&b, 0, sizeof(b));
+	b.d_text = d_text;
+	b.n = n;
+	b.halo = halo;
+	b.offset_shift = offset_shift;
+	b.init_state = init_state;
+	b.d_workspace = d_workspace;
+	b.workspace_bytes = workspace_bytes;
+	b.d_pat_plane = d_pat_plane;
+	b.d_off_plane = d_off_plane;
+	b.plane_capacity = plane_capacity;
+	b.stream = stream;
+	return acm_scan_batch_async(d, &b);
+}
+
+extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batch)
+{
+	if (!batch)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: null batch");
+	const void *d_text = batch->d_text;
+	const size_t n = batch->n, halo = batch->halo;
+	const long offset_shift = batch->offset_shift, init_state = batch->init_state;
+	void *d_workspace = batch->d_workspace;
+	const size_t workspace_bytes = batch->workspace_bytes;
+	int32_t *d_pat_plane = batch->d_pat_plane, *d_off_plane = batch->d_off_plane;
+	size_t plane_capacity = batch->plane_capacity;
+	void *stream = batch->stream;
 	if (!d || !d_pat_plane || !d_off_plane || plane_capacity < 2 || (n && !d_text))
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: bad arguments");
 	if (n > 0x7FFFFFEFul)
@@ -915,11 +943,16 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 				ACM_HIP_TRY(hipEventCreate(&e));
 			}
 		}
-		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	}
+	if (batch->wait_before_walk)
+		ACM_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)batch->wait_before_walk, 0));
+	if (d->profile)
+		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc = C == 4 ? launch_spec_walk<4>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
 	if (rc != ACM_OK)
 		return rc;
+	if (batch->record_after_walk)
+		ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
 	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2 blocks == scatter blocks

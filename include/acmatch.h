@@ -160,6 +160,33 @@ int acm_scan_shard_async(const acm_dfa *, const void *d_text, size_t n,
  * lane walks per tile (power of two, 16..256).  Returns the value in use. */
 int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
 
+/*
+ * Everything acm_scan_shard_async takes, plus two optional hipEvent_t for
+ * keeping several batches in flight on different streams (what the
+ * reference does with its -w workers, one queue each): the walk kernel is
+ * the stage that fills the device, so consecutive batches are chained
+ * through it -- batch k+1's walk waits for wait_before_walk (recorded by
+ * batch k as record_after_walk) -- while everything behind a walk runs
+ * concurrently with the next batch's walk.
+ */
+typedef struct acm_scan_batch {
+	const void *d_text;
+	size_t n;
+	size_t halo;
+	long offset_shift;
+	long init_state;
+	void *d_workspace;
+	size_t workspace_bytes;
+	int32_t *d_pat_plane;
+	int32_t *d_off_plane;
+	size_t plane_capacity;
+	void *stream;
+	void *wait_before_walk;		/* hipEvent_t or NULL */
+	void *record_after_walk;	/* hipEvent_t or NULL */
+} acm_scan_batch;
+
+int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
+
 /* independent chains each lane interleaves in the walk kernel: 2 or 4.
  * Returns the value in use. */
 int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
