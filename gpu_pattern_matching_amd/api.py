@@ -175,6 +175,26 @@ class Matcher:
     def set_chains_per_lane(self, c):
         return self.lib.acm_scan_set_chains_per_lane(self.dfa, c)
 
+    MODES = {"auto": 0, "chain": 1, "sparse": 2}
+    PATHS = {1: "chain", 2: "sparse", 3: "sparse->chain"}
+
+    def set_mode(self, mode):
+        """'auto' | 'chain' | 'sparse' (acm_scan_set_mode); returns the mode in use."""
+        got = self.lib.acm_scan_set_mode(self.dfa, self.MODES[mode])
+        return [k for k, v in self.MODES.items() if v == got][0]
+
+    def sparse_eligible(self):
+        return bool(self.lib.acm_scan_sparse_eligible(self.dfa))
+
+    def path_taken(self, n, stream=None, workspace=None):
+        """Which pipeline produced the planes of the last n-byte scan (synchronises)."""
+        st = stream if stream is not None else self.stream
+        ws_ptr = workspace[0] if workspace is not None else self.ws.ptr
+        rc = self.lib.acm_scan_path_taken(self.dfa, _ptr(ws_ptr), n, st)
+        if rc < 0:
+            check(rc, "acm_scan_path_taken")
+        return self.PATHS[rc]
+
     def scan_async(self, d_text, n, init_state=0, stream=None, pat_plane=None, off_plane=None,
                    plane_capacity=None, halo=0, offset_shift=0, workspace=None, wait_before_walk=None,
                    record_after_walk=None):

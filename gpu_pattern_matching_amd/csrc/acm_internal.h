@@ -31,6 +31,18 @@ constexpr uint32_t kHotRowsMax = 256;         // rows staged in LDS (256 * 512 B
 constexpr uint32_t kHotSentinel = 0xFFFFu;    // hot cell value meaning "look in the cold plane"
 constexpr uint32_t kNoPattern = 0xFFFFFFFFu;
 
+// trigram filter of the sparse pipeline (sparse.hip): a blocked Bloom filter,
+// both bits of a key in one 32-bit word, 128 KiB so it sits in one CU's LDS
+constexpr uint32_t kBloomLogWords = 15;
+constexpr uint32_t kBloomWords = 1u << kBloomLogWords;
+constexpr uint32_t kBloomMul1 = 0x9E3779u, kBloomMul2 = 0x85EBCAu;   // 24-bit odd multipliers
+inline uint32_t bloom_word(uint32_t tri) { return (uint32_t)(tri * kBloomMul1) >> (32 - kBloomLogWords); }
+inline uint32_t bloom_bits(uint32_t tri)
+{
+	const uint32_t p = (uint32_t)(tri * kBloomMul2);
+	return (1u << (p >> 27)) | (1u << ((p >> 22) & 31));
+}
+
 }  // namespace acm
 
 // Host automaton.  States carry two numberings:

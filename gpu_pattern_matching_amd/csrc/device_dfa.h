@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "acmatch.h"
+
 struct acm_dfa {
 	int device = 0;
 	int num_cus = 256;
@@ -19,7 +21,12 @@ struct acm_dfa {
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
 	uint8_t *d_in_byte = nullptr;        // [states + 32] byte on the edge into dev state
+	uint32_t *d_bloom = nullptr;         // [kBloomWords] trigrams of the depth-3 states (sparse pipeline)
+	uint32_t *d_t2g = nullptr;           // [65536] state after bytes (p, c) from the root, index p | c << 8
 	size_t device_bytes = 0;
+
+	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies
+	int scan_mode = ACM_SCAN_MODE_AUTO;
 
 	std::vector<uint32_t> ref2dev;       // host copy for init_state
 

@@ -26,6 +26,7 @@
 //                               so 16 expected bytes are one contiguous load
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -109,12 +110,40 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		if (rc == ACM_OK)
 			rc = upload(&d->d_dev2ref, a->dev2ref.data(), a->dev2ref.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
+
+		// sparse pipeline: Bloom filter over the byte triples that lead to a
+		// depth-3 state, and the depth <= 2 part of the DFA as a flat table
+		std::vector<uint32_t> bloom(acm::kBloomWords, 0), t2g(65536);
+		for (uint32_t s = 0; s < n; s++) {
+			const uint32_t r2 = a->dev2ref[s];
+			if (a->depth[r2] != 3)
+				continue;
+			const uint32_t r1 = a->parent[r2], r0 = a->parent[r1];
+			const uint32_t tri = (uint32_t)a->in_byte[r0] | ((uint32_t)a->in_byte[r1] << 8) |
+					     ((uint32_t)a->in_byte[r2] << 16);
+			bloom[acm::bloom_word(tri)] |= acm::bloom_bits(tri);
+		}
+		for (uint32_t p = 0; p < 256; p++) {
+			const uint32_t s1 = (uint32_t)rows[p];
+			for (uint32_t c = 0; c < 256; c++)
+				t2g[p | (c << 8)] = (uint32_t)rows[(size_t)s1 * 256 + c];
+		}
+		if (rc == ACM_OK) rc = upload(&d->d_bloom, bloom.data(), bloom.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_t2g, t2g.data(), t2g.size(), &d->device_bytes);
+		d->sparse_ok = !a->patterns.empty();
+		for (const auto &p : a->patterns)
+			if (p.bytes.size() < 3)
+				d->sparse_ok = false;
 	} catch (const std::bad_alloc &) {
 		rc = acm::fail(ACM_ERR_NOMEM, "acm_dfa_upload: out of host memory");
 	}
 	if (rc != ACM_OK) {
 		acm_dfa_release(d);
 		return rc;
+	}
+	if (const char *m = getenv("ACM_SCAN_MODE")) {   // debugging aid: same as acm_scan_set_mode
+		if (!strcmp(m, "chain")) d->scan_mode = ACM_SCAN_MODE_CHAIN;
+		else if (!strcmp(m, "sparse")) d->scan_mode = ACM_SCAN_MODE_SPARSE;
 	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess)
@@ -134,6 +163,8 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_out);
 		hipFree(d->d_dev2ref);
 		hipFree(d->d_in_byte);
+		hipFree(d->d_bloom);
+		hipFree(d->d_t2g);
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

@@ -52,9 +52,16 @@
 #include <cstring>
 
 #include "acm_internal.h"
+#include "deep_walk.h"
 #include "device_dfa.h"
+#include "sparse.h"
 
 namespace {
+
+using acm_dev::ChainText;
+using acm_dev::Deep;
+using acm_dev::deep_step;
+using acm_dev::fast_forward;
 
 constexpr int kBlock1 = 1024;          // K1 workgroup: 16 waves, one per CU (LDS bound)
 constexpr int kWaves1 = kBlock1 / 64;
@@ -102,6 +109,7 @@ struct ScanArgs {
 	int32_t *pat_plane;
 	int32_t *off_plane;
 	uint32_t plane_capacity;
+	const uint32_t *only_if;   // when set: run only if this device word is non-zero
 };
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
@@ -319,6 +327,8 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 template <int C>
 __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 {
+	if (a.only_if && *a.only_if == 0)
+		return;   // the sparse pipeline already produced the planes
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
 	{
 		// every workgroup copies the same table: start each one at a different
@@ -351,77 +361,6 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 // K2: deep walks
 // ---------------------------------------------------------------------------
 
-// byte m-1 (m = 1-based step) of the text starting at 16-byte aligned 'base';
-// a 16-byte group is loaded when the walk enters it, off the dependent chain
-struct ChainText {
-	const uint4 *p;
-	uint4 w;
-	uint32_t group;
-	__device__ __forceinline__ ChainText(const ScanArgs &a, uint32_t base)
-	    : p(a.text16 + (base >> 4)), group(0xFFFFFFFFu)
-	{
-		w = make_uint4(0, 0, 0, 0);
-	}
-	__device__ __forceinline__ uint32_t at(uint32_t m)
-	{
-		const uint32_t g = (m - 1) >> 4, k = (m - 1) & 15;
-		if (g != group) {
-			w = p[g];
-			group = g;
-		}
-		const uint32_t d = k < 8 ? (k < 4 ? w.x : w.y) : (k < 12 ? w.z : w.w);
-		return (d >> (8 * (k & 3))) & 0xFFu;
-	}
-};
-
-// the state a deep walk is in, with what the cell that produced it said
-struct Deep {
-	uint32_t s;       // dev id
-	uint32_t depth;   // trie depth of s
-	uint32_t run;     // unary, non-final trie path ahead: s+1, s+2, ... s+run
-};
-
-__device__ __forceinline__ Deep deep_step(const ScanArgs &a, uint32_t state, uint32_t byte)
-{
-	const size_t idx = ((size_t)state << 8) | byte;
-	const uint32_t next = a.cold[idx], m = a.meta[idx];   // two independent loads, one level
-	Deep d;
-	d.s = next;
-	d.depth = m & 0xFFFFu;
-	d.run = m >> 16;
-	return d;
-}
-
-// Fast-forward along the unary path ahead of d.  Text byte 'pos' is the next
-// one to consume, at most 'limit' bytes may be consumed.  While the text
-// agrees with the single outgoing edge of each state, the walk goes
-// s -> s+1 -> ...; none of the states entered is final and depth grows in
-// step with the bytes consumed (an unmerged walk stays unmerged).  One load
-// level moves the walk up to 16 bytes.  Returns the bytes consumed.
-__device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, Deep &d, uint32_t pos, uint32_t limit)
-{
-	uint32_t total = 0;
-	while (d.run != 0 && total < limit && pos + total + 16 <= a.n_pad) {
-		const uint32_t want = min(min(d.run, limit - total), 16u);
-		uint64_t e0, e1, t0, t1;
-		__builtin_memcpy(&e0, a.in_byte + d.s + 1, 8);
-		__builtin_memcpy(&e1, a.in_byte + d.s + 9, 8);
-		__builtin_memcpy(&t0, a.text + pos + total, 8);
-		__builtin_memcpy(&t1, a.text + pos + total + 8, 8);
-		const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
-		uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
-				   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
-		same = min(same, want);
-		d.s += same;
-		d.depth += same;
-		d.run -= same;
-		total += same;
-		if (same < want || same < 16)
-			break;   // mismatch, or the run / the limit ended inside this round
-	}
-	return total;
-}
-
 // K2a probe: lane c walks chain c from e[c-1] (the state chain c would start
 // in if chain c-1 has merged -- the overwhelmingly common case) until the
 // depth test says it has merged with chain c's own root walk.  It records
@@ -431,6 +370,8 @@ __device__ __forceinline__ uint32_t fast_forward(const ScanArgs &a, Deep &d, uin
 // Chains the walk kernel's epilogue already probed are skipped.
 __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 {
+	if (a.only_if && *a.only_if == 0)
+		return;   // the sparse pipeline already produced the planes
 	const uint32_t c = blockIdx.x * kBlock2 + threadIdx.x;
 	if (c >= a.n_chains)
 		return;
@@ -466,6 +407,8 @@ __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 // K2b resolve: one lane per chain (see the file header).
 __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 {
+	if (a.only_if && *a.only_if == 0)
+		return;   // the sparse pipeline already produced the planes
 	__shared__ uint32_t wave_fill[kBlock2 / 64];
 	__shared__ uint32_t wave_sum[kBlock2 / 64];
 	const uint32_t j = blockIdx.x * kBlock2 + threadIdx.x;
@@ -600,6 +543,8 @@ constexpr uint32_t kTopMax = kTopThreads * 64;
 
 __global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t nb)
 {
+	if (a.only_if && *a.only_if == 0)
+		return;   // the sparse pipeline already produced the planes
 	__shared__ int32_t tree[kTopThreads + (kTopThreads >> 5) + 1];
 	const int tid = threadIdx.x;
 	const uint32_t per = (nb + kTopThreads - 1) / kTopThreads;
@@ -647,6 +592,8 @@ __global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t n
 template <int C>
 __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 {
+	if (a.only_if && *a.only_if == 0)
+		return;   // the sparse pipeline already produced the planes
 	__shared__ uint32_t off[kBlock2];
 	__shared__ uint32_t wtot[kBlock2 / 64];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -729,7 +676,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
 	size_t end_state, c1f, k2info, wend, probe, rflag, cnt, off, wave_cnt1, wave_cnt2, misc, stage1,
-	    stage2, scan_ws;
+	    stage2, scan_ws, sparse;
 	size_t scan_ws_bytes;
 	size_t total;
 };
@@ -762,6 +709,7 @@ Layout layout_for(size_t max_text)
 	l.stage2 = take(stage_recs * 8);
 	l.scan_ws_bytes = acm_exclusive_scan_workspace_bytes(chains / kBlock2 + 2);
 	l.scan_ws = take(l.scan_ws_bytes);
+	l.sparse = take(acm::sparse_workspace_bytes(max_text));
 	l.total = o;
 	return l;
 }
@@ -808,6 +756,40 @@ extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 }
 
 extern "C" int acm_scan_kernel_count(void) { return 5; }
+
+namespace {
+// tiny texts are not worth the extra launches
+bool use_sparse(const acm_dfa *d, size_t n)
+{
+	return d->sparse_ok && d->scan_mode != ACM_SCAN_MODE_CHAIN && n >= 64;
+}
+}  // namespace
+
+extern "C" int acm_scan_set_mode(acm_dfa *d, int mode)
+{
+	if (!d)
+		return ACM_SCAN_MODE_CHAIN;
+	if (mode == ACM_SCAN_MODE_AUTO || mode == ACM_SCAN_MODE_CHAIN || mode == ACM_SCAN_MODE_SPARSE)
+		d->scan_mode = mode;
+	return d->scan_mode;
+}
+
+extern "C" int acm_scan_sparse_eligible(const acm_dfa *d) { return d && d->sparse_ok ? 1 : 0; }
+
+extern "C" int acm_scan_path_taken(const acm_dfa *d, const void *d_workspace, size_t n, void *stream)
+{
+	if (!d || !d_workspace)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_path_taken: bad arguments");
+	ACM_HIP_TRY(hipSetDevice(d->device));
+	ACM_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	if (!use_sparse(d, n))
+		return ACM_SCAN_MODE_CHAIN;
+	const Layout l = layout_for(n);
+	uint32_t gave_up = 0;
+	ACM_HIP_TRY(hipMemcpy(&gave_up, (const char *)d_workspace + l.sparse +
+	    acm::sparse_workspace_bytes(n) - 256, 4, hipMemcpyDeviceToHost));
+	return gave_up ? 3 : ACM_SCAN_MODE_SPARSE;
+}
 
 extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, long init_state,
     void *d_workspace, size_t workspace_bytes, int32_t *d_pat_plane, int32_t *d_off_plane,
@@ -948,7 +930,14 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		ACM_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)batch->wait_before_walk, 0));
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
-	int rc = C == 4 ? launch_spec_walk<4>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
+	int rc;
+	if (use_sparse(d, n)) {
+		// stage1 is free until the chain kernels run, and they run after these
+		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.stage1, s, &a.only_if);
+		if (rc != ACM_OK)
+			return rc;
+	}
+	rc = C == 4 ? launch_spec_walk<4>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
 	if (rc != ACM_OK)
 		return rc;
 	if (batch->record_after_walk)

@@ -191,8 +191,25 @@ int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
  * Returns the value in use. */
 int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
 
-/* number of kernels one acm_scan_async enqueues for a non-empty text */
+/* number of kernels one acm_scan_async enqueues for a non-empty text (chain pipeline) */
 int acm_scan_kernel_count(void);
+
+/* Which pipeline acm_scan_*_async runs.  Both produce the same planes.
+ *   CHAIN   speculative chains (any pattern set)
+ *   SPARSE  trigram filter + candidate walks; needs every pattern to have
+ *           at least 3 bytes (otherwise CHAIN is used); texts that exceed its
+ *           per-walker caps are redone by the chain pipeline inside the same
+ *           enqueue, decided on the device
+ *   AUTO    SPARSE when the pattern set allows it
+ * Returns the mode in use after the call; acm_scan_mode(d, -1) only queries. */
+enum { ACM_SCAN_MODE_AUTO = 0, ACM_SCAN_MODE_CHAIN = 1, ACM_SCAN_MODE_SPARSE = 2 };
+int acm_scan_set_mode(acm_dfa *, int mode);
+/* 1 when the pattern set qualifies for the sparse pipeline */
+int acm_scan_sparse_eligible(const acm_dfa *);
+/* after a scan of n bytes with this workspace has been enqueued on stream:
+ * waits for the stream and says which pipeline produced the planes --
+ * ACM_SCAN_MODE_CHAIN, ACM_SCAN_MODE_SPARSE, or 3 = sparse gave up, chain redid it */
+int acm_scan_path_taken(const acm_dfa *, const void *d_workspace, size_t n, void *stream);
 
 /* in-line timing with HIP events on the launch stream: when enabled, every
  * acm_scan_async records an event before the walk kernel, after it, and after

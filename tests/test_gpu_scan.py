@@ -50,14 +50,18 @@ GOLDEN_CASES = [(name, i) for name in GOLDEN for i in range(len(GOLDEN[name]["te
 
 @pytest.mark.parametrize("name,idx", GOLDEN_CASES,
                          ids=["%s-%s" % (n, fixtures.spec_id(GOLDEN[n]["texts"][i])) for n, i in GOLDEN_CASES])
-def test_golden_vectors(gpu, name, idx):
-    """Every golden vector, at BASELINE's full 32 MiB sizes too, by digest (no oracle needed)."""
+@pytest.mark.parametrize("mode", ["auto", "chain"])
+def test_golden_vectors(gpu, name, idx, mode):
+    """Every golden vector, at BASELINE's full 32 MiB sizes too, by digest (no oracle needed),
+    through the pipeline the library picks for the set and through the chain pipeline."""
     spec = GOLDEN[name]["texts"][idx]
     pats = fixtures.patterns_of(name) if spec["kind"] in ("clamav", "repeat") else None
     text = fixtures.text_for(spec, pats)
     assert hashlib.sha256(text.tobytes()).hexdigest() == spec["sha256"]
     m = matcher_for(name, max_text=max(text.size, 1 << 20))
+    m.set_mode(mode)
     pos, pat, last = m.scan(text)
+    m.set_mode("auto")
     assert pos.size == spec["count"]
     assert "%016x" % orc.records_digest(pos, pat) == spec["records_digest"]
     assert last == spec["final_state"]

@@ -1,0 +1,186 @@
+"""The sparse pipeline (trigram filter -> candidate walks -> prefix max -> scatter, sparse.hip)
+against the oracle and against the chain pipeline: same planes, bit for bit, whichever path
+produced them -- including the texts on which it gives up and the chain pipeline takes over
+inside the same enqueue.
+"""
+import numpy as np
+import pytest
+
+import fixtures
+import orc
+from gpu_pattern_matching_amd import Automaton, DeviceArray, Matcher
+
+pytestmark = pytest.mark.gpu
+
+
+def build(patterns):
+    a, o = Automaton(), orc.Oracle()
+    for i, p in enumerate(patterns):
+        a.add(p, i + 1)
+        o.add(p, i + 1)
+    a.compile()
+    o.compile()
+    return a, o
+
+
+def assert_same(got, exp):
+    assert got[0].size == exp[0].size, "record count %d != %d" % (got[0].size, exp[0].size)
+    assert np.array_equal(got[0], exp[0]), "offsets differ"
+    assert np.array_equal(got[1], exp[1]), "pattern indices differ"
+    assert got[2] == exp[2], "final state %d != %d" % (got[2], exp[2])
+
+
+def test_eligibility(gpu):
+    """Only sets whose shortest pattern has 3 bytes qualify; the others stay on the chain path."""
+    a, _ = build([b"abc", b"abcd", b"xyz12"])
+    m = Matcher(a, 0, max_text=4096)
+    assert m.sparse_eligible() and m.set_mode("sparse") == "sparse"
+    m.close()
+    a, o = build([b"abc", b"de"])
+    m = Matcher(a, 0, max_text=4096)
+    assert not m.sparse_eligible()
+    m.set_mode("sparse")
+    text = np.frombuffer(b"xxabcdexxdeabc" * 40, dtype=np.uint8)
+    assert_same(m.scan(text), o.scan(text))
+    assert m.path_taken(text.size) == "chain"
+    m.close()
+
+
+SMALL_SETS = {
+    "overlap": [b"abc", b"bcd", b"cde", b"abcde", b"aaa", b"cab", b"bca", b"eeeee", b"dcba"],
+    "nested": [b"abcabc", b"bcab", b"cabcab", b"abc", b"bbb", b"ccc", b"abcabcabcabc"],
+    "binary": [bytes([0, 0, 1]), bytes([1, 0, 0, 1]), bytes([255, 0, 255]), bytes([1, 1, 1, 1, 1, 1]),
+               bytes(range(16)), bytes([0, 1, 0, 1, 0, 1, 0])],
+}
+
+
+@pytest.mark.parametrize("setname", sorted(SMALL_SETS))
+@pytest.mark.parametrize("alphabet", [2, 3, 5, 26])
+def test_dense_candidates(gpu, setname, alphabet):
+    """Small alphabets: nearly every position is a candidate, deep runs overlap and chain into
+    each other, walkers start inside other walkers' runs -- the prefix-max rule decides who
+    reports what."""
+    pats = SMALL_SETS[setname]
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 18)
+    rng = np.random.default_rng(alphabet * 7 + len(setname))
+    letters = np.frombuffer(b"abcde" if setname != "binary" else bytes([0, 1, 255, 2, 3]),
+                            dtype=np.uint8)
+    for n in (64, 65, 200, 4096, 100003, 1 << 18):
+        if alphabet <= 5:
+            text = letters[rng.integers(0, min(alphabet, letters.size), size=n)]
+        else:
+            text = rng.integers(0, 256, size=n, dtype=np.uint8)
+            for _ in range(n // 50):   # plant patterns into the noise
+                p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+                at = int(rng.integers(0, max(1, n - p.size)))
+                text[at:at + p.size] = p[:n - at]
+        exp = o.scan(text)
+        got = {}
+        for mode in ("chain", "sparse"):
+            m.set_mode(mode)
+            got[mode] = m.scan(text)
+            assert_same(got[mode], exp)
+    m.close()
+
+
+def test_sparse_path_is_the_one_that_ran(gpu):
+    """On ordinary data the sparse kernels produce the planes (no silent fallback); on a text
+    that is one long deep run they give up and the chain pipeline redoes it."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=1 << 21)
+    a.close()
+    assert m.sparse_eligible()
+    m.set_mode("sparse")
+    text = fixtures.text_for({"kind": "clamav", "n": 1 << 21, "seed": 31, "n_plant": 2000}, pats)
+    assert_same(m.scan(text), o.scan(text))
+    assert m.path_taken(text.size) == "sparse"
+    p = pats[5]
+    rep = np.frombuffer((p * ((1 << 18) // len(p) + 1))[:1 << 18], dtype=np.uint8)
+    assert_same(m.scan(rep), o.scan(rep))
+    assert m.path_taken(rep.size) == "sparse->chain"
+    zeros = np.zeros(1 << 18, dtype=np.uint8)
+    assert_same(m.scan(zeros), o.scan(zeros))
+    m.close()
+
+
+def test_long_patterns_do_not_fall_back(gpu):
+    """A planted 2000-byte signature is one long unary path: the walker fast-forwards through
+    it, no cap is hit."""
+    rng = np.random.default_rng(5)
+    pats = [bytes(rng.integers(0, 256, size=k, dtype=np.uint8)) for k in (2000, 700, 64, 9, 3)]
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 20)
+    text = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
+    for i in range(200):
+        p = np.frombuffer(pats[i % len(pats)], dtype=np.uint8)
+        at = int(rng.integers(0, text.size - p.size))
+        text[at:at + p.size] = p
+    m.set_mode("sparse")
+    assert_same(m.scan(text), o.scan(text))
+    assert m.path_taken(text.size) == "sparse"
+    m.close()
+
+
+def test_carried_state_and_cuts(gpu):
+    """Streaming contract in sparse mode: cuts inside matches, 1..3 bytes after a match start,
+    carried last_state seeds the walker at position 0."""
+    pats = SMALL_SETS["nested"] + [b"needle-in-haystack", b"haystack"]
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 16)
+    m.set_mode("sparse")
+    rng = np.random.default_rng(9)
+    text = np.frombuffer(b"abc", dtype=np.uint8)[rng.integers(0, 3, size=40000)].copy()
+    for at in range(500, 39000, 1500):
+        text[at:at + 18] = np.frombuffer(b"needle-in-haystack", dtype=np.uint8)
+    whole = o.scan(text)
+    for piece in (64, 67, 100, 1000, 4097):
+        pos_all, pat_all, state = [], [], 0
+        for start in range(0, text.size, piece):
+            seg = text[start:start + piece]
+            pos, pat, state = m.scan(seg, state)
+            pos_all.append(pos.astype(np.int64) + start)
+            pat_all.append(pat)
+        assert np.array_equal(np.concatenate(pos_all), whole[0].astype(np.int64)), piece
+        assert np.array_equal(np.concatenate(pat_all), whole[1]), piece
+        assert state == whole[2]
+    m.close()
+
+
+def test_shard_halo_in_sparse_mode(gpu):
+    """acm_scan_shard_async: records ending in the halo are dropped, offsets shifted."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    text = fixtures.text_for({"kind": "clamav", "n": 1 << 19, "seed": 77, "n_plant": 800}, pats)
+    whole = o.scan(text)
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=text.size)
+    halo = a.max_pattern_len - 1
+    a.close()
+    m.set_mode("sparse")
+    parts = 4
+    per = text.size // parts + 3
+    pos_all, pat_all = [], []
+    for r in range(parts):
+        lo, hi = r * per, min(text.size, (r + 1) * per)
+        h = min(halo, lo)
+        d = DeviceArray.from_numpy(text[lo - h:hi])
+        m.scan_async(d, hi - lo + h, halo=h, offset_shift=lo - h)
+        pos, pat, _ = m.fetch()
+        assert m.path_taken(hi - lo + h) == "sparse"
+        d.free()
+        pos_all.append(pos)
+        pat_all.append(pat)
+    assert np.array_equal(np.concatenate(pos_all), whole[0])
+    assert np.array_equal(np.concatenate(pat_all), whole[1])
+    m.close()
