@@ -7,7 +7,9 @@
 
 Metric (BASELINE.json): input GB/s scanned (+ matches/s), 32 MB text x N ClamAV signatures.
 A step = one pass of the scan pipeline (walk -> probe -> resolve -> prefix sum -> scatter) over
-one 32 MiB batch already resident in HBM.  Like the reference, which keeps -w worker threads in
+one 32 MiB batch already resident in HBM (for signature sets whose shortest pattern has 3 bytes,
+as here, the library's sparse pipeline: trigram filter -> candidate walks -> prefix max -> count ->
+scatter; --mode chain forces the general one).  Like the reference, which keeps -w worker threads in
 flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144, :498-502),
 steps are issued round-robin on --workers HIP streams with private scratch, so the
 latency-bound tail of one batch overlaps the walk of the next.  With N > 1 GPUs the logical
@@ -52,6 +54,8 @@ def main():
     ap.add_argument("--chain-walks", action="store_true",
                     help="chain the walk kernels of consecutive batches with events (acm_scan_batch_async); "
                          "measured slower than letting the streams run free on MI355X")
+    ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
+                    help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
     ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,6 +105,7 @@ def main():
     states = aut.num_states
     matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
     matcher.set_chain_bytes(args.chain)
+    matcher.set_mode(args.mode)
     if args.cpl:
         matcher.set_chains_per_lane(args.cpl)
     aut.close()
@@ -195,21 +200,23 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_issued = time.perf_counter() - t0      # host time to enqueue everything (not a result)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
-    walk_ms, pipe_ms, launches = matcher.profile_read()
+    k1_ms, k2_ms, pipe_ms, launches = matcher.profile_read()
     # the same kernels with ONE batch in flight (outside the timed region): how long the walk
     # takes when it has the GPU to itself, for reading the roofline beside the shared figure
-    solo_walk_ms = solo_pipe_ms = 0.0
+    solo_k1_ms = solo_k2_ms = solo_pipe_ms = 0.0
     solo_n = 0
     if W > 1:
         for k in range(0, 10 * W, W):
             step(k)
             drain()
             torch.cuda.synchronize()
-        solo_walk_ms, solo_pipe_ms, solo_n = matcher.profile_read()
+        solo_k1_ms, solo_k2_ms, solo_pipe_ms, solo_n = matcher.profile_read()
     matcher.profile(False)
+    path = matcher.path_taken(n_local, workers[0].stream.cuda_stream, workspace=(workers[0].ws.data_ptr(), ws_bytes))
 
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
@@ -271,8 +278,18 @@ def main():
                        "all_cores": {"value": round(SHARD / t_all / 1e9, 4), "cores": ncpu}}
             o.close()
 
-        walk_s = walk_ms / 1e3 / max(launches, 1)
-        alg_bytes = n_local + 8 * m_local
+        # the kernel the roofline is quoted for: the longest one of the pipeline that ran.
+        # chain: k_spec_walk reads the text once and stages 8 B per record.  sparse: k_sparse_filter
+        # reads the text once and writes one candidate bit per byte; k_sparse_walk reads those bits
+        # and stages 8 B per record (it is latency bound: a few thousand dependent table walks).
+        L1 = max(launches, 1)
+        if path == "chain":
+            kernels = [("k_spec_walk", k1_ms, solo_k1_ms, n_local + 8 * m_local)]
+        else:
+            kernels = [("k_sparse_filter", k1_ms, solo_k1_ms, n_local + n_local // 8),
+                       ("k_sparse_walk", k2_ms, solo_k2_ms, n_local // 8 + 8 * m_local)]
+        kname, kms, ksolo_ms, alg_bytes = max(kernels, key=lambda t: t[1])
+        walk_s = kms / 1e3 / L1
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         value = total_bytes * args.steps / elapsed / 1e9
         # HBM bytes per launch of the walk kernel from the PMC passes of this same command
@@ -281,8 +298,8 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tfile) and args.sigs == 2000 and args.max_len < 0:
-            for kname, rec in json.load(open(tfile)).items():
-                if "k_spec_walk" in kname:
+            for name, rec in json.load(open(tfile)).items():
+                if kname in name:
                     traffic = round(rec["hbm_bytes_per_launch"], 1)
         out = {
             "metric": "input_GB_per_s_scanned",
@@ -299,23 +316,25 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "32 MiB per GPU of seeded uniform bytes + %d planted signatures x first %d "
-                            "ClamAV sigs%s (%d states, max len %d); scan -> resolve -> prefix-sum -> "
-                            "scatter, match planes gathered to rank 0" % (
+                            "ClamAV sigs%s (%d states, max len %d); scan -> ordered compact "
+                            "(offset, pattern) planes, gathered to rank 0" % (
                                 args.plant, args.sigs,
                                 "" if args.max_len < 0 else " (-m %d)" % args.max_len, states, L),
                 "text_bytes_per_gpu": SHARD,
                 "signatures": args.sigs,
+                "pipeline": path,
                 "chain_bytes": matcher.set_chain_bytes(args.chain) or "auto",
                 "batches_in_flight": W,
                 "parallelism": "text sharded %d-way, DFA replicated" % world,
             },
+            "host_enqueue_us_per_step": round(t_issued / args.steps * 1e6, 2),
             "matches_per_step": m_total,
             "matches_per_s": round(m_total * args.steps / elapsed, 1),
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 5),
             "parity": parity,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_spec_walk",
+                "kernel": kname,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -324,14 +343,16 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": round(walk_s * 1e6, 2),
                 "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
+                "kernels_us": {k[0]: round(k[1] / L1 * 1e3, 2) for k in kernels},
                 "note": "HIP events on each batch's own stream inside the timed region; with %d batches "
-                        "in flight the walk shares the GPU with the other batch's kernels" % W,
+                        "in flight a kernel shares the GPU with the other batches' kernels" % W,
             },
         }
         if solo_n:
-            sw = solo_walk_ms / 1e3 / solo_n
+            sw = ksolo_ms / 1e3 / solo_n
             out["roofline_one_batch_in_flight"] = {
                 "kernel_us": round(sw * 1e6, 2),
+                "kernels_us": {k[0]: round(k[2] / solo_n * 1e3, 2) for k in kernels},
                 "pipeline_us": round(solo_pipe_ms / solo_n * 1e3, 2),
                 "achieved": round(alg_bytes / sw / 1e9, 2),
                 "frac": round(alg_bytes / sw / 1e9 / HBM_PEAK_GBS, 5),

@@ -69,7 +69,7 @@ NATIVE_API = {
     "acm_scan_sparse_eligible": (C.c_int, [_vp]),
     "acm_scan_path_taken": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "acm_scan_profile_enable": (C.c_int, [_vp, C.c_int]),
-    "acm_scan_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+    "acm_scan_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int)]),
     "acm_exclusive_scan_workspace_bytes": (C.c_size_t, [C.c_size_t]),
     "acm_exclusive_scan_i32": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),

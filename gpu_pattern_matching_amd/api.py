@@ -255,10 +255,11 @@ class Matcher:
         check(self.lib.acm_scan_profile_enable(self.dfa, int(enable)), "acm_scan_profile_enable")
 
     def profile_read(self):
-        w, p, n = C.c_double(), C.c_double(), C.c_int()
-        check(self.lib.acm_scan_profile_read(self.dfa, C.byref(w), C.byref(p), C.byref(n)),
+        """(first kernel ms, second kernel ms, pipeline ms, launches) since the last read."""
+        f, s2, p, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self.lib.acm_scan_profile_read(self.dfa, C.byref(f), C.byref(s2), C.byref(p), C.byref(n)),
               "acm_scan_profile_read")
-        return w.value, p.value, n.value
+        return f.value, s2.value, p.value, n.value
 
     def close(self):
         for b in (self.ws, self.pat_plane, self.off_plane):

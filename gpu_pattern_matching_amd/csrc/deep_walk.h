@@ -14,23 +14,24 @@ namespace acm_dev {
 // a 16-byte group is loaded when the walk enters it, off the dependent chain
 struct ChainText {
 	const uint4 *p;
-	uint4 w;
+	uint64_t lo, hi;   // the 16-byte group as two words (a uint4 member ends up as a private array in LDS)
 	uint32_t group;
 	template <class A>
 	__device__ __forceinline__ ChainText(const A &a, uint32_t base)
-	    : p(a.text16 + (base >> 4)), group(0xFFFFFFFFu)
+	    : p(a.text16 + (base >> 4)), lo(0), hi(0), group(0xFFFFFFFFu)
 	{
-		w = make_uint4(0, 0, 0, 0);
 	}
 	__device__ __forceinline__ uint32_t at(uint32_t m)
 	{
 		const uint32_t g = (m - 1) >> 4, k = (m - 1) & 15;
 		if (g != group) {
-			w = p[g];
+			const uint4 w = p[g];
+			lo = (uint64_t)w.x | ((uint64_t)w.y << 32);
+			hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
 			group = g;
 		}
-		const uint32_t d = k < 8 ? (k < 4 ? w.x : w.y) : (k < 12 ? w.z : w.w);
-		return (d >> (8 * (k & 3))) & 0xFFu;
+		const uint64_t half = k < 8 ? lo : hi;
+		return (uint32_t)(half >> (8 * (k & 7))) & 0xFFu;
 	}
 };
 
@@ -53,24 +54,41 @@ __device__ __forceinline__ Deep deep_step(const A &a, uint32_t state, uint32_t b
 	return d;
 }
 
+// XOR of the 16 bytes at two arbitrarily aligned addresses, as two 64-bit
+// words: each side comes from the five aligned dwords that cover it (plain
+// registers all the way -- a by-value 16-byte object here ends up as a private
+// array the compiler parks in LDS).  Reads up to p + 20 / q + 20.
+__device__ __forceinline__ uint32_t dword_at(const uint32_t *q, uint32_t i, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbyte(q[i + 1], q[i], sh);
+}
+
+__device__ __forceinline__ void diff_bytes16(const uint8_t *p, const uint8_t *q, uint64_t &lo, uint64_t &hi)
+{
+	const uint32_t *pa = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+	const uint32_t *qa = (const uint32_t *)((uintptr_t)q & ~(uintptr_t)3);
+	const uint32_t ps = (uint32_t)((uintptr_t)p & 3), qs = (uint32_t)((uintptr_t)q & 3);
+	const uint32_t x0 = dword_at(pa, 0, ps) ^ dword_at(qa, 0, qs), x1 = dword_at(pa, 1, ps) ^ dword_at(qa, 1, qs);
+	const uint32_t x2 = dword_at(pa, 2, ps) ^ dword_at(qa, 2, qs), x3 = dword_at(pa, 3, ps) ^ dword_at(qa, 3, qs);
+	lo = (uint64_t)x0 | ((uint64_t)x1 << 32);
+	hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+}
+
 // Fast-forward along the unary path ahead of d.  Text byte 'pos' is the next
 // one to consume, at most 'limit' bytes may be consumed.  While the text
 // agrees with the single outgoing edge of each state, the walk goes
 // s -> s+1 -> ...; none of the states entered is final and depth grows in
 // step with the bytes consumed (an unmerged walk stays unmerged).  One load
-// level moves the walk up to 16 bytes.  Returns the bytes consumed.
+// level moves the walk up to 16 bytes.  Returns the bytes consumed.  (Stops
+// 20 bytes short of the padded end of the text: the caller single-steps there.)
 template <class A>
 __device__ __forceinline__ uint32_t fast_forward(const A &a, Deep &d, uint32_t pos, uint32_t limit)
 {
 	uint32_t total = 0;
-	while (d.run != 0 && total < limit && pos + total + 16 <= a.n_pad) {
+	while (d.run != 0 && total < limit && pos + total + 20 <= a.n_pad) {
 		const uint32_t want = min(min(d.run, limit - total), 16u);
-		uint64_t e0, e1, t0, t1;
-		__builtin_memcpy(&e0, a.in_byte + d.s + 1, 8);
-		__builtin_memcpy(&e1, a.in_byte + d.s + 9, 8);
-		__builtin_memcpy(&t0, a.text + pos + total, 8);
-		__builtin_memcpy(&t1, a.text + pos + total + 8, 8);
-		const uint64_t x0 = e0 ^ t0, x1 = e1 ^ t1;
+		uint64_t x0, x1;
+		diff_bytes16(a.in_byte + d.s + 1, a.text + pos + total, x0, x1);
 		uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
 				   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
 		same = min(same, want);
@@ -83,6 +101,5 @@ __device__ __forceinline__ uint32_t fast_forward(const A &a, Deep &d, uint32_t p
 	}
 	return total;
 }
-
 
 }  // namespace acm_dev

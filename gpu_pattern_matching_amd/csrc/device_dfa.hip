@@ -32,6 +32,7 @@
 
 #include "acm_internal.h"
 #include "device_dfa.h"
+#include "sparse.h"
 
 extern "C" int acm_device_count(void)
 {
@@ -140,6 +141,10 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 	if (rc != ACM_OK) {
 		acm_dfa_release(d);
 		return rc;
+	}
+	if (d->sparse_ok && acm::sparse_prepare(d) != ACM_OK) {
+		acm_dfa_release(d);
+		return ACM_ERR_HIP;
 	}
 	if (const char *m = getenv("ACM_SCAN_MODE")) {   // debugging aid: same as acm_scan_set_mode
 		if (!strcmp(m, "chain")) d->scan_mode = ACM_SCAN_MODE_CHAIN;

@@ -67,6 +67,7 @@ constexpr int kBlock1 = 1024;          // K1 workgroup: 16 waves, one per CU (LD
 constexpr int kWaves1 = kBlock1 / 64;
 constexpr int kBlock2 = 256;
 constexpr uint32_t kNoFirst = 0xFFFFu;
+constexpr uint32_t kFallbackHotRows = 32;   // LDS rows of the walk when it is the sparse pipeline's fallback
 constexpr uint8_t kProbeTodo = 0xFF;
 
 struct ScanArgs {
@@ -915,7 +916,7 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		return ACM_OK;
 	}
 
-	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
 	if (d->profile) {
 		for (auto &e : ev) {
 			if (!d->profile_pool.empty()) {  // recycled: no create/destroy in a timed loop
@@ -932,8 +933,11 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
 	if (use_sparse(d, n)) {
-		// stage1 is free until the chain kernels run, and they run after these
-		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.stage1, s, &a.only_if);
+		// the walk behind the sparse kernels is an early-exit launch nearly always: keep its LDS
+		// request small, so that placing it does not wait for a CU another stream's filter kernel
+		// (128 KiB of LDS) occupies.  Fewer hot rows only move lookups to the cold plane.
+		a.H = a.H < kFallbackHotRows ? a.H : kFallbackHotRows;
+		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, s, &a.only_if, ev[1], ev[2]);
 		if (rc != ACM_OK)
 			return rc;
 	}
@@ -942,8 +946,10 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		return rc;
 	if (batch->record_after_walk)
 		ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
-	if (d->profile)
+	if (d->profile && !a.only_if) {   // chain pipeline on its own: the walk is the first stage, no second
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
+		ACM_HIP_TRY(hipEventRecord(ev[2], s));
+	}
 	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2 blocks == scatter blocks
 	hipLaunchKernelGGL(k_probe, dim3(nb), dim3(kBlock2), 0, s, a);
 	hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(kBlock2), 0, s, a);
@@ -963,7 +969,7 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		hipLaunchKernelGGL(k_scatter_all<2>, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
 	if (d->profile) {
-		ACM_HIP_TRY(hipEventRecord(ev[2], s));
+		ACM_HIP_TRY(hipEventRecord(ev[3], s));
 		for (auto e : ev)
 			d->profile_events.push_back((void *)e);
 	}
@@ -978,28 +984,32 @@ extern "C" int acm_scan_profile_enable(acm_dfa *d, int enable)
 	return ACM_OK;
 }
 
-extern "C" int acm_scan_profile_read(acm_dfa *d, double *walk_ms, double *pipeline_ms, int *launches)
+extern "C" int acm_scan_profile_read(acm_dfa *d, double *first_ms, double *second_ms, double *pipeline_ms,
+    int *launches)
 {
 	if (!d)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_profile_read: null dfa");
-	double walk = 0, pipe = 0;
+	double first = 0, second = 0, pipe = 0;
 	int n = 0;
-	for (size_t i = 0; i + 2 < d->profile_events.size(); i += 3) {
-		hipEvent_t e0 = (hipEvent_t)d->profile_events[i], e1 = (hipEvent_t)d->profile_events[i + 1],
-			   e2 = (hipEvent_t)d->profile_events[i + 2];
-		float a = 0, b = 0;
-		ACM_HIP_TRY(hipEventSynchronize(e2));
-		ACM_HIP_TRY(hipEventElapsedTime(&a, e0, e1));
-		ACM_HIP_TRY(hipEventElapsedTime(&b, e0, e2));
-		walk += a;
-		pipe += b;
+	for (size_t i = 0; i + 3 < d->profile_events.size(); i += 4) {
+		hipEvent_t e[4];
+		for (int k = 0; k < 4; k++)
+			e[k] = (hipEvent_t)d->profile_events[i + k];
+		float a = 0, b = 0, c = 0;
+		ACM_HIP_TRY(hipEventSynchronize(e[3]));
+		ACM_HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+		ACM_HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+		ACM_HIP_TRY(hipEventElapsedTime(&c, e[0], e[3]));
+		first += a;
+		second += b;
+		pipe += c;
 		n++;
-		d->profile_pool.push_back((void *)e0);
-		d->profile_pool.push_back((void *)e1);
-		d->profile_pool.push_back((void *)e2);
+		for (int k = 0; k < 4; k++)
+			d->profile_pool.push_back((void *)e[k]);
 	}
 	d->profile_events.clear();
-	if (walk_ms) *walk_ms = walk;
+	if (first_ms) *first_ms = first;
+	if (second_ms) *second_ms = second;
 	if (pipeline_ms) *pipeline_ms = pipe;
 	if (launches) *launches = n;
 	return ACM_OK;

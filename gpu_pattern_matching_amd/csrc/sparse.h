@@ -15,11 +15,13 @@ namespace acm {
 // bytes of private workspace the sparse pipeline needs for texts up to max_text
 size_t sparse_workspace_bytes(size_t max_text);
 
-// Enqueue the sparse pipeline for 'b' on stream s.  stage_area: >= 8 bytes per
-// text byte (rounded up to 64), may be reused by whatever runs afterwards on
-// the stream.  *gate = device word that is non-zero when the planes were NOT
-// produced and the chain pipeline has to run.
+// once per device DFA: kernel attributes
+int sparse_prepare(const acm_dfa *d);
+
+// Enqueue the sparse pipeline for 'b' on stream s.  *gate = device word that is
+// non-zero when the planes were NOT produced and the chain pipeline has to run.
+// after_filter / after_walk: events to record behind the first two kernels, or null.
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    void *stage_area, hipStream_t s, const uint32_t **gate);
+    hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk);
 
 }  // namespace acm

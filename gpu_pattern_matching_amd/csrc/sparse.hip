@@ -1,9 +1,8 @@
-// The sparse scan pipeline: trigram filter -> candidate walks -> prefix max ->
-// count -> ordered scatter.  gfx950 only.  Same contract and output as the
-// chain pipeline of scan.hip (it is the second implementation of
-// acm_scan_*_async, chosen at upload for pattern sets whose shortest pattern
-// has at least 3 bytes); scan.hip stays the general path and the in-launch
-// fallback.
+// The sparse scan pipeline: trigram filter -> candidate walks with in-kernel
+// dedup, count and ordered scatter.  gfx950 only.  Same contract and output as
+// the chain pipeline of scan.hip (it is the second implementation of
+// acm_scan_*_async, chosen for pattern sets whose shortest pattern has at
+// least 3 bytes); scan.hip stays the general path and the in-enqueue fallback.
 //
 // Why it is exact.  The serial DFA state at text position k is the longest
 // suffix of the text that is a trie node.  While that depth is <= 2 the state
@@ -18,27 +17,37 @@
 //                         negatives).  No state, no dependent load, fully
 //                         coalesced text reads: this is the bulk pass.
 //                         Output: one candidate bit per text byte.
-//   SW1 k_sparse_walk     one walker per run of consecutive candidate bits:
+//   SW  k_sparse_walk     one walker per run of consecutive candidate bits:
 //                         start in T2[bytes a-2, a-1] at position a and walk
 //                         the DFA exactly (cold/meta planes, fast-forward)
 //                         while the state is deep or the next position is a
-//                         candidate.  Hits and the walker's deep extent
-//                         [a, end] are staged per 64-position word.  A walker
-//                         that started while an earlier deep run was still
-//                         alive walks suffix-states of the true ones until
-//                         that run ends, and exact states after it.
-//   max-scan + SW2/SS     walker j keeps its hits at positions > M_j, the
-//                         largest 'end' of the walkers before it (exclusive
-//                         prefix max in position order): exactly the part of
-//                         its walk no earlier walker covers.  Counts are
-//                         scanned and the kept hits land in position order.
+//                         candidate.  A walker that started while an earlier
+//                         deep run was still alive walks suffix-states of the
+//                         true ones until that run ends, and exact states
+//                         after it.  Hence the rule: walker j keeps its hits
+//                         at positions > M_j, the largest deep extent of the
+//                         walkers before it in position order -- exactly the
+//                         part of its walk no earlier walker covers.  M_j is
+//                         an exclusive prefix max; the part of it inside the
+//                         workgroup (shuffles within a wave, LDS across
+//                         waves) is applied here.  Hits stay in LDS while the
+//                         walkers run (on gfx9 a store in flight holds up the
+//                         next dependent load); at the end the workgroup
+//                         writes its surviving hits in position order and its
+//                         largest deep extent.
+//   SE  k_sparse_emit     one workgroup: prefix max of the workgroup extents,
+//                         drops the hits an earlier workgroup's walker covers
+//                         (a prefix of each sorted list), prefix sum of what
+//                         is left, ordered scatter into the planes, header
+//                         and trailer cells.  A few thousand values: latency,
+//                         not bandwidth.
 //
 // The state carried into the buffer (init_state) is handled by a walker at
-// position 0 that starts from it.  A walker is capped (kIterCap table steps, 64
-// staged records per word); texts that exceed the caps -- very long deep
-// runs, e.g. a page of the byte a signature starts with three times -- raise
-// a device flag and the chain pipeline, enqueued right behind and otherwise
-// a row of early-exit launches, produces the planes instead.
+// position 0 that starts from it.  Work is capped -- table steps per walker,
+// walkers per 4096 positions, hits per 16384 positions; texts beyond the caps
+// (one endless deep run, a match at every byte) raise a device flag and the
+// chain pipeline, enqueued right behind and otherwise a row of early-exit
+// launches, produces the planes instead.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -52,17 +61,19 @@
 
 namespace {
 
+using acm::kBloomWords;
 using acm_dev::ChainText;
 using acm_dev::Deep;
 using acm_dev::deep_step;
 using acm_dev::fast_forward;
 
 constexpr int kFilterBlock = 1024;
-constexpr int kWordBlock = 256;            // words (of 64 text positions) per SW block
-constexpr uint32_t kRecPerWord = 64;       // staged records per word (aliases the chain staging area)
+constexpr int kWordBlock = 256;            // words (of 64 text positions) per SE workgroup
+constexpr int kWordWaves = kWordBlock / 64;
 constexpr uint32_t kIterCap = 256;         // table steps one walker may take ...
 constexpr uint32_t kForwardCap = 4096;     // ... each followed by this many fast-forwarded bytes at most
-constexpr uint32_t kHdr = 0x80000000u;
+constexpr uint32_t kMaxWalkWave = 128;     // walkers per wave (4096 positions)
+constexpr uint32_t kMaxHits = 128;         // staged hits per workgroup (16384 positions)
 
 struct SparseArgs {
 	const uint32_t *cold, *meta;
@@ -80,15 +91,12 @@ struct SparseArgs {
 	int32_t off_shift;
 	uint32_t nwords, nblocks;
 	// workspace
-	uint16_t *mask;           // [n_pad / 16 + 8] candidate bits
-	int32_t *maxend;          // [nwords] largest deep extent of the word's walkers, -1 if none
-	uint32_t *nrec;           // [nwords] staged records (headers + hits)
-	uint32_t *cnt;            // [nwords] kept hits
-	int32_t *bmax;            // [nblocks] per-block max of maxend, then exclusive prefix max
-	int32_t *boff;            // [nblocks] per-block kept hits, then exclusive prefix sum
-	uint2 *stage;             // [nwords][kRecPerWord]
-	uint32_t *flags;          // [0] overflow -> fall back, [1] total
-	unsigned long long *keeper;   // start position << 32 | state of the first walker that reached the end
+	uint16_t *mask;                // [n_pad / 16 + 8] candidate bits
+	uint32_t *block_extent;        // [nblocks] largest deep extent + 1 of the workgroup's walkers
+	uint32_t *block_hits;          // [nblocks] hits the workgroup staged
+	uint2 *hit_list;               // [nblocks][kMaxHits] {position, state}, ascending positions
+	uint32_t *flags;               // [0] gave up -> chain pipeline runs
+	unsigned long long *keeper;    // start position << 32 | state of the first walker that reached the end
 	// output
 	int32_t *pat_plane, *off_plane;
 	uint32_t plane_capacity;
@@ -96,20 +104,22 @@ struct SparseArgs {
 
 // ------------------------------------------------------------------ SF ---
 
+// bit 0 of the result: both filter bits of the trigram (low 24 bits of tri) are set
 __device__ __forceinline__ uint32_t bloom_test(const uint32_t *bloom, uint32_t tri)
 {
 	const uint32_t p1 = __umul24(tri, acm::kBloomMul1), p2 = __umul24(tri, acm::kBloomMul2);
 	const uint32_t w = bloom[p1 >> (32 - acm::kBloomLogWords)];
-	return (w >> (p2 >> 27)) & (w >> ((p2 >> 22) & 31)) & 1u;
+	return (w >> (p2 >> 27)) & (w >> ((p2 >> 22) & 31));
 }
 
+// shifts the candidate bit of position K of the 16-byte group into m from the top
 template <int K>
-__device__ __forceinline__ uint32_t probe(const uint32_t *bloom, const uint32_t (&x)[5])
+__device__ __forceinline__ uint32_t probe(const uint32_t *bloom, const uint32_t (&x)[5], uint32_t m)
 {
-	// bytes (K-2, K-1, K) of the 16-byte group; x[0] is the dword in front of it
+	// bytes (K-2, K-1, K) of the group; x[0] is the dword in front of it
 	constexpr int lo = (K + 2) / 4, sh = (K + 2) % 4;
 	const uint32_t v = sh == 0 ? x[lo] : __builtin_amdgcn_alignbyte(x[lo + 1 > 4 ? 4 : lo + 1], x[lo], sh);
-	return bloom_test(bloom, v & 0xFFFFFFu) << K;
+	return __builtin_amdgcn_alignbit(bloom_test(bloom, v), m, 1);
 }
 
 // persistent: one workgroup per CU keeps the filter in LDS; a wave-iteration
@@ -120,13 +130,17 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 	{
 		const uint4 *src = (const uint4 *)a.bloom;
 		uint4 *dst = (uint4 *)bloom;
-		constexpr uint32_t n16 = acm::kBloomWords / 4;
+		constexpr uint32_t n16 = kBloomWords / 4;
 		const uint32_t rot = (blockIdx.x * 1021u) % n16;
 		for (uint32_t i = threadIdx.x; i < n16; i += kFilterBlock) {
 			uint32_t j = i + rot;
 			j = j >= n16 ? j - n16 : j;
 			dst[j] = src[j];
 		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {   // first kernel of the pipeline: reset what the others accumulate into
+		a.flags[0] = 0;
+		*a.keeper = ~0ull;
 	}
 	__syncthreads();
 	const uint32_t n16 = a.n_pad >> 4;
@@ -144,10 +158,11 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 		const uint32_t prev = i16 ? text32[i16 * 4 - 1] : 0u;
 		const uint32_t x[5] = { prev, w.x, w.y, w.z, w.w };
 		uint32_t m = 0;
-		m |= probe<0>(bloom, x); m |= probe<1>(bloom, x); m |= probe<2>(bloom, x); m |= probe<3>(bloom, x);
-		m |= probe<4>(bloom, x); m |= probe<5>(bloom, x); m |= probe<6>(bloom, x); m |= probe<7>(bloom, x);
-		m |= probe<8>(bloom, x); m |= probe<9>(bloom, x); m |= probe<10>(bloom, x); m |= probe<11>(bloom, x);
-		m |= probe<12>(bloom, x); m |= probe<13>(bloom, x); m |= probe<14>(bloom, x); m |= probe<15>(bloom, x);
+		m = probe<0>(bloom, x, m); m = probe<1>(bloom, x, m); m = probe<2>(bloom, x, m); m = probe<3>(bloom, x, m);
+		m = probe<4>(bloom, x, m); m = probe<5>(bloom, x, m); m = probe<6>(bloom, x, m); m = probe<7>(bloom, x, m);
+		m = probe<8>(bloom, x, m); m = probe<9>(bloom, x, m); m = probe<10>(bloom, x, m); m = probe<11>(bloom, x, m);
+		m = probe<12>(bloom, x, m); m = probe<13>(bloom, x, m); m = probe<14>(bloom, x, m); m = probe<15>(bloom, x, m);
+		m >>= 16;
 		if (i16 == 0)
 			m &= ~3u;                        // no full trigram yet: the position-0 walker covers these
 		const uint32_t pos0 = i16 << 4;
@@ -157,34 +172,34 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 	}
 }
 
-// ----------------------------------------------------------------- SW1 ---
+// ------------------------------------------------------------------ SE ---
 
-struct WordOut {
-	uint2 *region;
-	uint32_t nrec;
-	int32_t maxend;
-	bool overflow;
+// hits of one workgroup, in LDS until they are written to the planes
+struct HitList {
+	uint32_t pos[kMaxHits];
+	uint32_t state[kMaxHits];
+	uint32_t owner[kMaxHits];   // wave << 16 | walker index within the wave; bit 31: dropped
+	uint32_t count;             // may run past kMaxHits: then the workgroup gave up
 };
 
-__device__ __forceinline__ bool mask_bit(const SparseArgs &a, uint32_t p)
+// One walker: from the state before position p0 over p0, p0 + 1, ... while the
+// state is deep or the next position is a candidate.  end_out: the last deep
+// position (-1: none).  Returns false when a cap was hit.
+__device__ __forceinline__ bool walker(const SparseArgs &a, HitList &hits, const uint64_t *lmask, uint32_t word0,
+    uint32_t owner, uint32_t p0, int32_t &end_out)
 {
-	return (a.mask[p >> 4] >> (p & 15)) & 1u;
-}
-
-// walk from 'state' (the state before position p0) over positions p0, p0+1, ...
-__device__ __forceinline__ void walker(const SparseArgs &a, WordOut &o, uint32_t start_tag, uint32_t state,
-    uint32_t p0, uint32_t min_steps)
-{
-	if (o.nrec >= kRecPerWord) {
-		o.overflow = true;
-		return;
+	uint32_t state, min_steps = 0;
+	if (p0 == 0) {
+		state = a.init_state;
+		min_steps = 2;   // positions 0 and 1 have no candidate bit of their own
+	} else {
+		state = a.t2g[(uint32_t)a.text[p0 - 2] | ((uint32_t)a.text[p0 - 1] << 8)];
 	}
-	const uint32_t hdr = o.nrec++;
 	int32_t end = -1;
 	uint32_t p = p0, iters = 0;
 	const uint32_t tbase = p0 & ~15u;
 	ChainText txt(a, tbase);
-	bool reached_end = false;
+	bool reached_end = false, ok = true;
 	for (;;) {
 		if (p >= a.n) {
 			reached_end = true;
@@ -196,11 +211,14 @@ __device__ __forceinline__ void walker(const SparseArgs &a, WordOut &o, uint32_t
 		if (deep)
 			end = (int32_t)p;
 		if (state >= a.F && p >= a.drop_before) {
-			if (o.nrec >= kRecPerWord) {
-				o.overflow = true;
+			const uint32_t slot = atomicAdd(&hits.count, 1u);
+			if (slot >= kMaxHits) {
+				ok = false;
 				break;
 			}
-			o.region[o.nrec++] = make_uint2(p, state);
+			hits.pos[slot] = p;
+			hits.state[slot] = state;
+			hits.owner[slot] = owner;
 		}
 		if (deep && d.run != 0 && state < a.F) {
 			// k more deep, non-final positions along a unary trie path, 16 per load level
@@ -210,205 +228,212 @@ __device__ __forceinline__ void walker(const SparseArgs &a, WordOut &o, uint32_t
 			end = (int32_t)p;
 		}
 		p++;
-		if (!deep && p - p0 >= min_steps && (p >= a.n || !mask_bit(a, p))) {
-			reached_end = p >= a.n;
-			break;
-		}
-		if (++iters >= kIterCap) {
-			o.overflow = true;
-			break;
-		}
-	}
-	o.region[hdr] = make_uint2(start_tag, kHdr | (uint32_t)(end + 1));
-	if (end > o.maxend)
-		o.maxend = end;
-	if (reached_end)   // the earliest such walker is exact at the last byte: it carries last_state
-		atomicMin(a.keeper, ((unsigned long long)start_tag << 32) | state);
-}
-
-__global__ __launch_bounds__(kWordBlock) void k_sparse_walk(SparseArgs a)
-{
-	__shared__ int32_t wmax[kWordBlock / 64];
-	const uint32_t w = blockIdx.x * kWordBlock + threadIdx.x;
-	int32_t mymax = -1;
-	if (w < a.nwords) {
-		const uint64_t m = *(const uint64_t *)(a.mask + (size_t)w * 4);
-		const uint64_t prev = w ? (uint64_t)(a.mask[(size_t)w * 4 - 1] >> 15) : 0ull;
-		uint64_t starts = m & ~((m << 1) | prev);
-		WordOut o;
-		o.region = a.stage + (size_t)w * kRecPerWord;
-		o.nrec = 0;
-		o.maxend = -1;
-		o.overflow = false;
-		if (w == 0)   // the state carried into the buffer
-			walker(a, o, 0u, a.init_state, 0u, 2u);
-		while (starts) {
-			const uint32_t b = (uint32_t)__ffsll((long long)starts) - 1;
-			starts &= starts - 1;
-			const uint32_t pos = (w << 6) + b;   // >= 2: bits 0 and 1 of the text are never set
-			const uint32_t st = a.t2g[(uint32_t)a.text[pos - 2] | ((uint32_t)a.text[pos - 1] << 8)];
-			walker(a, o, pos, st, pos, 0u);
-			if (o.overflow)
+		if (!deep && p - p0 >= min_steps) {
+			if (p >= a.n) {
+				reached_end = true;
+				break;
+			}
+			// candidate bit of position p: in LDS for the wave's own 4096 positions
+			const uint32_t wi = (p >> 6) - word0;
+			const uint64_t mbits = wi < 64 ? lmask[wi] : *(const uint64_t *)(a.mask + (size_t)(p >> 6) * 4);
+			if (!((mbits >> (p & 63)) & 1ull))
 				break;
 		}
-		a.nrec[w] = o.nrec;
-		a.maxend[w] = o.maxend;
-		mymax = o.maxend;
-		if (o.overflow)
-			a.flags[0] = 1;
+		if (++iters >= kIterCap) {
+			ok = false;
+			break;
+		}
 	}
-#pragma unroll
-	for (int s = 32; s > 0; s >>= 1)
-		mymax = max(mymax, __shfl_down(mymax, s, 64));
-	if ((threadIdx.x & 63) == 0)
-		wmax[threadIdx.x >> 6] = mymax;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int32_t t = -1;
-		for (int i = 0; i < kWordBlock / 64; i++)
-			t = max(t, wmax[i]);
-		a.bmax[blockIdx.x] = t;
-	}
+	end_out = end;
+	if (reached_end)   // the earliest such walker is exact at the last byte: it carries last_state
+		atomicMin(a.keeper, ((unsigned long long)p0 << 32) | state);
+	return ok;
 }
 
-// ------------------------------------------------------- top-level scans ---
-
-constexpr int kTopThreads = 1024;
-
-// exclusive prefix max (IS_MAX) or sum of up to 64K block values by one workgroup, in place
-template <bool IS_MAX>
-__global__ __launch_bounds__(kTopThreads) void k_sparse_top(int32_t *v, uint32_t nb, uint32_t *total_out)
+__global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 {
-	__shared__ int32_t part[kTopThreads];
-	const int tid = threadIdx.x;
-	const uint32_t per = (nb + kTopThreads - 1) / kTopThreads;
-	const uint32_t lo = min(nb, (uint32_t)tid * per), hi = min(nb, lo + per);
-	const int32_t ident = IS_MAX ? -1 : 0;
-	int32_t acc = ident;
-	for (uint32_t i = lo; i < hi; i++)
-		acc = IS_MAX ? max(acc, v[i]) : acc + v[i];
-	part[tid] = acc;
-	__syncthreads();
-	// Hillis-Steele inclusive scan over the 1024 partials
-	for (int o = 1; o < kTopThreads; o <<= 1) {
-		int32_t t = ident;
-		if (tid >= o)
-			t = part[tid - o];
-		__syncthreads();
-		if (tid >= o)
-			part[tid] = IS_MAX ? max(part[tid], t) : part[tid] + t;
-		__syncthreads();
-	}
-	int32_t run = tid ? part[tid - 1] : ident;
-	if (!IS_MAX && total_out && tid == kTopThreads - 1)
-		*total_out = (uint32_t)part[tid];
-	for (uint32_t i = lo; i < hi; i++) {
-		const int32_t x = v[i];
-		v[i] = run;
-		run = IS_MAX ? max(run, x) : run + x;
-	}
-}
-
-// ------------------------------------------------------------ SW2 / SS ---
-
-// exclusive prefix of 'mine' over the block's words, on top of 'base'
-template <bool IS_MAX>
-__device__ __forceinline__ int32_t block_exclusive(int32_t mine, int32_t base, int32_t *lds)
-{
+	__shared__ HitList hits;
+	__shared__ uint64_t lmask[kWordWaves][64];               // candidate bits of the wave's words
+	__shared__ int32_t walker_m[kWordWaves][kMaxWalkWave];   // max deep extent of the wave's walkers before k
+	__shared__ int32_t wave_max[kWordWaves];
+	__shared__ uint32_t s_gave_up, s_survivors;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int32_t ident = IS_MAX ? -1 : 0;
-	int32_t inc = mine;
+	if (threadIdx.x == 0) {
+		hits.count = 0;
+		s_gave_up = 0;
+		s_survivors = 0;
+	}
+	__syncthreads();
+	const uint32_t w = blockIdx.x * kWordBlock + threadIdx.x;
+
+	// the walkers of this wave's 64 words (4096 positions), in position order
+	uint64_t starts = 0, m = 0;
+	if (w < a.nwords) {
+		m = *(const uint64_t *)(a.mask + (size_t)w * 4);
+		const uint64_t prev = w ? (uint64_t)(a.mask[(size_t)w * 4 - 1] >> 15) : 0ull;
+		starts = m & ~((m << 1) | prev);   // first bit of every run of candidate bits
+		if (w == 0)
+			starts |= 1ull;                // the walker that carries init_state (bits 0, 1 are never candidates)
+	}
+	lmask[wv][lane] = m;
+	const uint32_t cnt = (uint32_t)__popcll(starts);
+	uint32_t inc = cnt;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
-		const int32_t t = __shfl_up(inc, o, 64);
+		const uint32_t t = __shfl_up(inc, o, 64);
 		if (lane >= (uint32_t)o)
-			inc = IS_MAX ? max(inc, t) : inc + t;
+			inc += t;
 	}
-	int32_t excl = __shfl_up(inc, 1, 64);
+	const uint32_t total = __shfl(inc, 63, 64), base = inc - cnt;
+	bool ok = total <= kMaxWalkWave;   // wave-uniform
+	int32_t carry = -1;                // largest deep extent of the wave's walkers so far
+	const uint32_t rounds = ok ? (total + 63) / 64 : 0;
+	for (uint32_t r = 0; r < rounds; r++) {   // walker k runs on lane k % 64, whichever word it starts in
+		const uint32_t k = r * 64 + lane;
+		const bool valid = k < total;
+		uint32_t owner_lane = 0;               // the last lane whose first walker index is <= k
+#pragma unroll
+		for (int step = 32; step > 0; step >>= 1) {
+			const uint32_t cand = owner_lane + step;
+			const uint32_t b = __shfl(base, cand & 63, 64);
+			if (cand < 64 && b <= k)
+				owner_lane = cand;
+		}
+		const uint32_t lo = __shfl((uint32_t)starts, owner_lane, 64);
+		const uint32_t hi = __shfl((uint32_t)(starts >> 32), owner_lane, 64);
+		const uint32_t first = __shfl(base, owner_lane, 64);
+		int32_t end = -1;
+		if (valid) {
+			uint64_t s = ((uint64_t)hi << 32) | lo;
+			for (uint32_t i = first; i < k; i++)
+				s &= s - 1;
+			const uint32_t p0 = ((w - lane + owner_lane) << 6) + (uint32_t)__ffsll((long long)s) - 1;
+			ok &= walker(a, hits, lmask[wv], w - lane, (wv << 16) | k, p0, end);
+		}
+		int32_t incm = end;   // inclusive prefix max over the round, then exclusive + earlier rounds
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int32_t t = __shfl_up(incm, o, 64);
+			if (lane >= (uint32_t)o)
+				incm = max(incm, t);
+		}
+		int32_t excl = __shfl_up(incm, 1, 64);
+		if (lane == 0)
+			excl = -1;
+		if (valid)
+			walker_m[wv][k] = max(carry, excl);
+		carry = max(carry, __shfl(incm, 63, 64));
+	}
+	if (!ok)
+		s_gave_up = 1;
 	if (lane == 0)
-		excl = ident;
+		wave_max[wv] = carry;
+	__syncthreads();
+
+	// drop the hits an earlier walker of this workgroup covers
+	const uint32_t nh = min(hits.count, kMaxHits);
+	for (uint32_t i = threadIdx.x; i < nh; i += kWordBlock) {
+		const uint32_t o = hits.owner[i], ow = o >> 16;
+		int32_t m = walker_m[ow][o & 0xFFFFu];
+		for (uint32_t v = 0; v < ow; v++)
+			m = max(m, wave_max[v]);
+		if ((int32_t)hits.pos[i] <= m)
+			hits.owner[i] = o | 0x80000000u;
+	}
+	__syncthreads();
+	// the others have distinct positions: rank = number of survivors in front
+	uint32_t survivors = 0;
+	for (uint32_t i = threadIdx.x; i < nh; i += kWordBlock) {
+		if (hits.owner[i] & 0x80000000u)
+			continue;
+		const uint32_t pos = hits.pos[i];
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < nh; j++)
+			rank += (!(hits.owner[j] & 0x80000000u) && hits.pos[j] < pos) ? 1u : 0u;
+		a.hit_list[(size_t)blockIdx.x * kMaxHits + rank] = make_uint2(pos, hits.state[i]);
+		survivors++;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		survivors += __shfl_xor(survivors, o, 64);
+	if (lane == 0 && survivors)
+		atomicAdd(&s_survivors, survivors);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int32_t bm = -1;
+		for (int i = 0; i < kWordWaves; i++)
+			bm = max(bm, wave_max[i]);
+		a.block_extent[blockIdx.x] = (uint32_t)(bm + 1);
+		a.block_hits[blockIdx.x] = s_survivors;
+		if (s_gave_up)
+			a.flags[0] = 1;
+	}
+}
+
+constexpr int kEmitBlock = 1024;
+
+// exclusive scan (max or sum) of one value per thread over the workgroup; *total = the full reduction
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, uint32_t *total)
+{
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint32_t incl = x;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(incl, o, 64);
+		if (lane >= (uint32_t)o)
+			incl = IS_MAX ? max(incl, t) : incl + t;
+	}
+	uint32_t excl = __shfl_up(incl, 1, 64);
+	if (lane == 0)
+		excl = 0;
 	if (lane == 63)
-		lds[wv] = inc;
+		lds[wv] = incl;
 	__syncthreads();
-	int32_t before = base;
-	for (uint32_t i = 0; i < wv; i++)
-		before = IS_MAX ? max(before, lds[i]) : before + lds[i];
+	uint32_t before = 0, all = 0;
+	for (uint32_t i = 0; i < kEmitBlock / 64; i++) {
+		const uint32_t v = lds[i];
+		if (i < wv)
+			before = IS_MAX ? max(before, v) : before + v;
+		all = IS_MAX ? max(all, v) : all + v;
+	}
 	__syncthreads();
+	*total = all;
 	return IS_MAX ? max(before, excl) : before + excl;
 }
 
-// SW2: how many of the word's staged hits survive (position > what earlier walkers cover)
-__global__ __launch_bounds__(kWordBlock) void k_sparse_count(SparseArgs a)
+__global__ __launch_bounds__(kEmitBlock) void k_sparse_emit(SparseArgs a)
 {
-	__shared__ int32_t lds[kWordBlock / 64];
-	__shared__ uint32_t wsum[kWordBlock / 64];
+	__shared__ uint32_t lds[kEmitBlock / 64];
 	if (a.flags[0])
-		return;   // capped: the chain pipeline behind us produces the result
-	const uint32_t w = blockIdx.x * kWordBlock + threadIdx.x;
-	const int32_t mine = w < a.nwords ? a.maxend[w] : -1;
-	int32_t cur = block_exclusive<true>(mine, a.bmax[blockIdx.x], lds);
-	uint32_t kept = 0;
-	if (w < a.nwords) {
-		const uint2 *region = a.stage + (size_t)w * kRecPerWord;
-		const uint32_t nrec = a.nrec[w];
-		int32_t thresh = cur;
-		for (uint32_t r = 0; r < nrec; r++) {
-			const uint2 rec = region[r];
-			if (rec.y & kHdr) {
-				thresh = cur;
-				cur = max(cur, (int32_t)(rec.y & ~kHdr) - 1);
-			} else if ((int32_t)rec.x > thresh) {
-				kept++;
+		return;   // a cap was hit: the chain pipeline behind this kernel produces the planes
+	uint32_t extent_before = 0, cells_before = 0;   // over the workgroups of earlier passes
+	for (uint32_t first = 0; first < a.nblocks; first += kEmitBlock) {
+		const uint32_t b = first + threadIdx.x;
+		const bool live = b < a.nblocks;
+		const uint32_t extent = live ? a.block_extent[b] : 0u;
+		const uint32_t staged = live ? a.block_hits[b] : 0u;
+		uint32_t pass_extent, pass_cells;
+		const uint32_t covered = max(extent_before, block_exclusive<true>(extent, lds, &pass_extent));
+		// the list is sorted: what an earlier workgroup's walker covers is a prefix of it
+		const uint2 *list = a.hit_list + (size_t)b * kMaxHits;
+		uint32_t dropped = 0;
+		while (dropped < staged && list[dropped].x < covered)
+			dropped++;
+		const uint32_t kept = staged - dropped;
+		uint32_t d = cells_before + block_exclusive<false>(kept, lds, &pass_cells);
+		for (uint32_t i = dropped; i < staged; i++, d++) {
+			const uint2 rec = list[i];
+			if (d + 2 < a.plane_capacity) {
+				a.pat_plane[1 + d] = a.out[rec.y];
+				a.off_plane[1 + d] = (int32_t)rec.x + a.off_shift;
 			}
 		}
-		a.cnt[w] = kept;
+		extent_before = max(extent_before, pass_extent);
+		cells_before += pass_cells;
 	}
-	uint32_t s = kept;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		s += __shfl_down(s, o, 64);
-	if ((threadIdx.x & 63) == 0)
-		wsum[threadIdx.x >> 6] = s;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t t = 0;
-		for (int i = 0; i < kWordBlock / 64; i++)
-			t += wsum[i];
-		a.boff[blockIdx.x] = (int32_t)t;
-	}
-}
-
-// SS: write the surviving hits in position order + header/trailer cells
-__global__ __launch_bounds__(kWordBlock) void k_sparse_scatter(SparseArgs a)
-{
-	__shared__ int32_t lds[kWordBlock / 64];
-	if (a.flags[0])
-		return;
-	const uint32_t w = blockIdx.x * kWordBlock + threadIdx.x;
-	const int32_t mine = w < a.nwords ? a.maxend[w] : -1;
-	int32_t cur = block_exclusive<true>(mine, a.bmax[blockIdx.x], lds);
-	const int32_t kept = w < a.nwords ? (int32_t)a.cnt[w] : 0;
-	uint32_t d = (uint32_t)block_exclusive<false>(kept, a.boff[blockIdx.x], lds);
-	if (w < a.nwords && kept) {
-		const uint2 *region = a.stage + (size_t)w * kRecPerWord;
-		const uint32_t nrec = a.nrec[w];
-		int32_t thresh = cur;
-		for (uint32_t r = 0; r < nrec; r++) {
-			const uint2 rec = region[r];
-			if (rec.y & kHdr) {
-				thresh = cur;
-				cur = max(cur, (int32_t)(rec.y & ~kHdr) - 1);
-			} else if ((int32_t)rec.x > thresh) {
-				if (d + 2 < a.plane_capacity) {
-					a.pat_plane[1 + d] = a.out[rec.y];
-					a.off_plane[1 + d] = (int32_t)rec.x + a.off_shift;
-				}
-				d++;
-			}
-		}
-	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		const uint32_t total = a.flags[1];
+	if (threadIdx.x == 0) {   // header and trailer cells
+		const uint32_t total_hits = cells_before;
 		uint32_t last;
 		const unsigned long long k = *a.keeper;
 		if (k != ~0ull)
@@ -416,11 +441,11 @@ __global__ __launch_bounds__(kWordBlock) void k_sparse_scatter(SparseArgs a)
 		else                      // depth <= 2 at the end: the state is a function of the last two bytes
 			last = a.t2g[(uint32_t)a.text[a.n - 2] | ((uint32_t)a.text[a.n - 1] << 8)];
 		const int32_t last_ref = (int32_t)a.dev2ref[last];
-		uint32_t tail = total + 1;
+		uint32_t tail = total_hits + 1;
 		if (tail > a.plane_capacity - 1)
 			tail = a.plane_capacity - 1;
-		a.pat_plane[0] = (int32_t)total;
-		a.off_plane[0] = (int32_t)total;
+		a.pat_plane[0] = (int32_t)total_hits;
+		a.off_plane[0] = (int32_t)total_hits;
 		a.pat_plane[tail] = last_ref;
 		a.off_plane[tail] = last_ref;
 	}
@@ -434,19 +459,24 @@ namespace acm {
 
 size_t sparse_workspace_bytes(size_t max_text)
 {
-	const size_t words = max_text / 64 + 2, blocks = words / kWordBlock + 2;
+	const size_t blocks = (max_text / 64 + 2) / kWordBlock + 2;
 	size_t o = 0;
 	o += align_up((max_text / 16 + 16) * 2, 256);   // mask
-	o += align_up(words * 4, 256) * 3;               // maxend, nrec, cnt
-	o += align_up(blocks * 4, 256) * 2;              // bmax, boff
+	o += align_up(blocks * 4, 256) * 2;              // per-workgroup extent, hit count
+	o += align_up(blocks * kMaxHits * 8, 256);       // per-workgroup hit lists
 	o += 256;                                        // flags + keeper
 	return o;
 }
 
-// enqueue the sparse pipeline; *gate receives the device address of the flag
-// the chain pipeline must test (non-zero -> run)
+int sparse_prepare(const acm_dfa *)
+{
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sparse_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
+	    (int)(kBloomWords * 4)));
+	return ACM_OK;
+}
+
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    void *stage_area, hipStream_t s, const uint32_t **gate)
+    hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk)
 {
 	const size_t n = b->n;
 	SparseArgs a;
@@ -475,36 +505,30 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		o += align_up(bytes, 256);
 		return p;
 	};
-	const size_t words = n / 64 + 2, blocks = words / kWordBlock + 2;
+	const size_t blocks = (n / 64 + 2) / kWordBlock + 2;
 	a.mask = (uint16_t *)take((n / 16 + 16) * 2);
-	a.maxend = (int32_t *)take(words * 4);
-	a.nrec = (uint32_t *)take(words * 4);
-	a.cnt = (uint32_t *)take(words * 4);
-	a.bmax = (int32_t *)take(blocks * 4);
-	a.boff = (int32_t *)take(blocks * 4);
+	a.block_extent = (uint32_t *)take(blocks * 4);
+	a.block_hits = (uint32_t *)take(blocks * 4);
+	a.hit_list = (uint2 *)take(blocks * kMaxHits * 8);
 	a.flags = (uint32_t *)take(256);
 	a.keeper = (unsigned long long *)(a.flags + 8);
-	a.stage = (uint2 *)stage_area;
 	a.pat_plane = b->d_pat_plane;
 	a.off_plane = b->d_off_plane;
 	a.plane_capacity = (uint32_t)(b->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : b->plane_capacity);
 	*gate = a.flags;
 
-	ACM_HIP_TRY(hipMemsetAsync(a.flags, 0, 32, s));
-	ACM_HIP_TRY(hipMemsetAsync(a.keeper, 0xFF, 8, s));
 	const size_t lds = (size_t)kBloomWords * 4;
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sparse_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
-	    (int)lds));
 	const uint32_t wave_iters = (a.n_pad / 16 + 8 + 63) / 64;
 	uint32_t fblocks = (wave_iters + kFilterBlock / 64 - 1) / (kFilterBlock / 64);
 	if (fblocks > (uint32_t)d->num_cus)
 		fblocks = (uint32_t)d->num_cus;
 	hipLaunchKernelGGL(k_sparse_filter, dim3(fblocks), dim3(kFilterBlock), lds, s, a);
+	if (after_filter)
+		ACM_HIP_TRY(hipEventRecord(after_filter, s));
 	hipLaunchKernelGGL(k_sparse_walk, dim3(a.nblocks), dim3(kWordBlock), 0, s, a);
-	hipLaunchKernelGGL(k_sparse_top<true>, dim3(1), dim3(kTopThreads), 0, s, a.bmax, a.nblocks, (uint32_t *)nullptr);
-	hipLaunchKernelGGL(k_sparse_count, dim3(a.nblocks), dim3(kWordBlock), 0, s, a);
-	hipLaunchKernelGGL(k_sparse_top<false>, dim3(1), dim3(kTopThreads), 0, s, a.boff, a.nblocks, a.flags + 1);
-	hipLaunchKernelGGL(k_sparse_scatter, dim3(a.nblocks), dim3(kWordBlock), 0, s, a);
+	if (after_walk)
+		ACM_HIP_TRY(hipEventRecord(after_walk, s));
+	hipLaunchKernelGGL(k_sparse_emit, dim3(1), dim3(kEmitBlock), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }

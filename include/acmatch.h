@@ -212,13 +212,15 @@ int acm_scan_sparse_eligible(const acm_dfa *);
 int acm_scan_path_taken(const acm_dfa *, const void *d_workspace, size_t n, void *stream);
 
 /* in-line timing with HIP events on the launch stream: when enabled, every
- * acm_scan_async records an event before the walk kernel, after it, and after
- * the last kernel.  acm_scan_profile_read waits for the recorded events,
- * returns the summed milliseconds of the walk kernel and of the whole
- * pipeline over 'launches' calls, and resets the accumulation. */
+ * acm_scan_async records an event before its first kernel, after its first
+ * kernel (chain: the walk; sparse: the trigram filter), after its second
+ * (sparse: the candidate walk; chain: none, 0 ms) and after its last.
+ * acm_scan_profile_read waits for the recorded events, returns the summed
+ * milliseconds of the first kernel, the second, and the whole pipeline over
+ * 'launches' calls, and resets the accumulation. */
 int acm_scan_profile_enable(acm_dfa *, int enable);
-int acm_scan_profile_read(acm_dfa *, double *walk_ms, double *pipeline_ms,
-    int *launches);
+int acm_scan_profile_read(acm_dfa *, double *first_ms, double *second_ms,
+    double *pipeline_ms, int *launches);
 
 /* ---------------------------------------------------------------------- */
 /* standalone result post-processing ops (device pointers, async)          */

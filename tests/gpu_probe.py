@@ -103,7 +103,7 @@ def main():
             m.scan_async(d_text, n)
         lib.acm_rt_device_sync()
         t1 = time.perf_counter()
-        w, pl, cnt = m.profile_read()
+        w, _, pl, cnt = m.profile_read()
         m.profile(False)
         log("S=%-3d wall %.1f us/scan  walk %.1f us  pipeline %.1f us  -> %.1f GB/s (walk %.1f GB/s)" % (
             S, (t1 - t0) / K * 1e6, w / cnt * 1e3, pl / cnt * 1e3, n / ((t1 - t0) / K) / 1e9,

@@ -103,10 +103,19 @@ def test_sparse_path_is_the_one_that_ran(gpu):
     assert m.path_taken(text.size) == "sparse"
     p = pats[5]
     rep = np.frombuffer((p * ((1 << 18) // len(p) + 1))[:1 << 18], dtype=np.uint8)
-    assert_same(m.scan(rep), o.scan(rep))
-    assert m.path_taken(rep.size) == "sparse->chain"
+    assert_same(m.scan(rep), o.scan(rep))          # a deep run per repetition: still sparse
     zeros = np.zeros(1 << 18, dtype=np.uint8)
     assert_same(m.scan(zeros), o.scan(zeros))
+    m.close()
+    a, o = build(SMALL_SETS["nested"])
+    m = Matcher(a, 0, max_text=1 << 18)
+    m.set_mode("sparse")
+    endless = np.frombuffer(b"abc" * 80000, dtype=np.uint8)   # one deep run, a hit every byte or so
+    assert_same(m.scan(endless), o.scan(endless))
+    assert m.path_taken(endless.size) == "sparse->chain"
+    quiet = np.frombuffer(b"abd" * 80000, dtype=np.uint8)
+    assert_same(m.scan(quiet), o.scan(quiet))
+    assert m.path_taken(quiet.size) == "sparse"
     m.close()
 
 
@@ -183,4 +192,26 @@ def test_shard_halo_in_sparse_mode(gpu):
         pat_all.append(pat)
     assert np.array_equal(np.concatenate(pos_all), whole[0])
     assert np.array_equal(np.concatenate(pat_all), whole[1])
+    m.close()
+
+
+def test_beyond_the_fused_block_limit(gpu):
+    """Above 128 MiB the block prefix max / prefix sum are separate single-workgroup kernels
+    (below, every block reduces the values in front of it itself): both arrangements agree with
+    the oracle."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    n = (129 << 20) + 12345
+    text = fixtures.text_for({"kind": "clamav", "n": n, "seed": 3, "n_plant": 20000}, pats)
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=n)
+    a.close()
+    m.set_mode("sparse")
+    exp = o.scan(text)
+    assert_same(m.scan(text), exp)
+    assert m.path_taken(n) == "sparse"
     m.close()
