@@ -50,18 +50,27 @@ def main():
     ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
     ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
     ap.add_argument("--plant", type=int, default=4096)
-    ap.add_argument("--workers", type=int, default=2, help="batches in flight (HIP streams)")
+    ap.add_argument("--workers", type=int, default=4, help="batches in flight (HIP streams)")
     ap.add_argument("--chain-walks", action="store_true",
                     help="chain the walk kernels of consecutive batches with events (acm_scan_batch_async); "
                          "measured slower than letting the streams run free on MI355X")
     ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
                     help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay the HIP graph the library captures for a repeating batch instead of "
+                         "launching every kernel of every step (acm_scan_set_graphs; measured neutral)")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="record the library's HIP events (kernel durations for the roofline) on every K-th "
+                         "timed step; those steps are launched kernel by kernel, the others replay the graph")
     ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
+    # one hardware queue per batch in flight: with HIP's default of 4 queues per process the
+    # streams of 4 workers (+ torch's own) share queues and serialise (measured: 43 vs 27 us/step)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,6 +115,7 @@ def main():
     matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
     matcher.set_chain_bytes(args.chain)
     matcher.set_mode(args.mode)
+    graphs = matcher.set_graphs(args.graphs)
     if args.cpl:
         matcher.set_chains_per_lane(args.cpl)
     aut.close()
@@ -196,10 +206,15 @@ def main():
         step(k)
     drain()
     fence()
-    matcher.profile(True)
+    pe = max(1, args.profile_every)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        if k % pe == 0:
+            matcher.profile(True)
+            step(k)
+            matcher.profile(False)
+        else:
+            step(k)
     t_issued = time.perf_counter() - t0      # host time to enqueue everything (not a result)
     drain()
     fence()
@@ -209,6 +224,7 @@ def main():
     # takes when it has the GPU to itself, for reading the roofline beside the shared figure
     solo_k1_ms = solo_k2_ms = solo_pipe_ms = 0.0
     solo_n = 0
+    matcher.profile(True)
     if W > 1:
         for k in range(0, 10 * W, W):
             step(k)
@@ -323,8 +339,10 @@ def main():
                 "text_bytes_per_gpu": SHARD,
                 "signatures": args.sigs,
                 "pipeline": path,
+                "hip_graphs": graphs,
                 "chain_bytes": matcher.set_chain_bytes(args.chain) or "auto",
                 "batches_in_flight": W,
+                "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way, DFA replicated" % world,
             },
             "host_enqueue_us_per_step": round(t_issued / args.steps * 1e6, 2),
@@ -344,8 +362,10 @@ def main():
                 "kernel_us": round(walk_s * 1e6, 2),
                 "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
                 "kernels_us": {k[0]: round(k[1] / L1 * 1e3, 2) for k in kernels},
-                "note": "HIP events on each batch's own stream inside the timed region; with %d batches "
-                        "in flight a kernel shares the GPU with the other batches' kernels" % W,
+                "launches_timed": launches,
+                "note": "HIP events on the batch's own stream around the kernels of every %d-th step of the "
+                        "timed region; with %d batches in flight a kernel shares the GPU with the other "
+                        "batches' kernels" % (pe, W),
             },
         }
         if solo_n:

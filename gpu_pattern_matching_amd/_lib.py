@@ -66,6 +66,7 @@ NATIVE_API = {
     "acm_scan_set_chains_per_lane": (C.c_int, [_vp, C.c_int]),
     "acm_scan_kernel_count": (C.c_int, []),
     "acm_scan_set_mode": (C.c_int, [_vp, C.c_int]),
+    "acm_scan_set_graphs": (C.c_int, [_vp, C.c_int]),
     "acm_scan_sparse_eligible": (C.c_int, [_vp]),
     "acm_scan_path_taken": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "acm_scan_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -183,6 +183,10 @@ class Matcher:
         got = self.lib.acm_scan_set_mode(self.dfa, self.MODES[mode])
         return [k for k, v in self.MODES.items() if v == got][0]
 
+    def set_graphs(self, enable):
+        """Replay repeating scans as HIP graphs (acm_scan_set_graphs); returns the setting in use."""
+        return bool(self.lib.acm_scan_set_graphs(self.dfa, int(enable)))
+
     def sparse_eligible(self):
         return bool(self.lib.acm_scan_sparse_eligible(self.dfa))
 

@@ -373,6 +373,9 @@ void *worker_main(void *arg)
 
 int main(int argc, char **argv)
 {
+	// one hardware queue per worker stream (HIP's default is 4 per process; streams that share a
+	// queue serialise).  Has to be in the environment before the first HIP call.
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	Shared sh;
 	Config &c = sh.cfg;
 	int opt;

@@ -32,11 +32,12 @@ constexpr uint32_t kHotSentinel = 0xFFFFu;    // hot cell value meaning "look in
 constexpr uint32_t kNoPattern = 0xFFFFFFFFu;
 
 // trigram filter of the sparse pipeline (sparse.hip): a blocked Bloom filter,
-// both bits of a key in one 32-bit word, 128 KiB so it sits in one CU's LDS
-constexpr uint32_t kBloomLogWords = 15;
-constexpr uint32_t kBloomWords = 1u << kBloomLogWords;
+// both bits of a key in one 32-bit word; 2^10 .. 2^15 words (4 .. 128 KiB of
+// LDS), sized at upload to about 4 words per key
+constexpr uint32_t kBloomMinLogWords = 10, kBloomMaxLogWords = 15;
+constexpr uint32_t kBloomMaxWords = 1u << kBloomMaxLogWords;
 constexpr uint32_t kBloomMul1 = 0x9E3779u, kBloomMul2 = 0x85EBCAu;   // 24-bit odd multipliers
-inline uint32_t bloom_word(uint32_t tri) { return (uint32_t)(tri * kBloomMul1) >> (32 - kBloomLogWords); }
+inline uint32_t bloom_word(uint32_t tri, uint32_t log_words) { return (uint32_t)(tri * kBloomMul1) >> (32 - log_words); }
 inline uint32_t bloom_bits(uint32_t tri)
 {
 	const uint32_t p = (uint32_t)(tri * kBloomMul2);

@@ -1,7 +1,7 @@
 // Device helpers shared by the chain pipeline (scan.hip) and the sparse
-// pipeline (sparse.hip): exact DFA walking over the cold/meta planes with
+// pipeline (sparse.hip): exact DFA walking over the deep plane with
 // fast-forward along unary trie paths.  'A' is any kernel-argument struct
-// with members cold, meta, in_byte, text, text16, n_pad.
+// with members deep, in_byte, text, text16, n_pad.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -46,7 +46,8 @@ template <class A>
 __device__ __forceinline__ Deep deep_step(const A &a, uint32_t state, uint32_t byte)
 {
 	const size_t idx = ((size_t)state << 8) | byte;
-	const uint32_t next = a.cold[idx], m = a.meta[idx];   // two independent loads, one level
+	const uint64_t cell = a.deep[idx];   // target | depth << 32 | run << 48: one load, one TLB entry
+	const uint32_t next = (uint32_t)cell, m = (uint32_t)(cell >> 32);
 	Deep d;
 	d.s = next;
 	d.depth = m & 0xFFFFu;
@@ -74,24 +75,32 @@ __device__ __forceinline__ void diff_bytes16(const uint8_t *p, const uint8_t *q,
 	hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
 }
 
+// bytes two 16-byte windows agree on before the first difference (16: all)
+__device__ __forceinline__ uint32_t agree16(const uint8_t *p, const uint8_t *q)
+{
+	uint64_t x0, x1;
+	diff_bytes16(p, q, x0, x1);
+	return x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
+		  : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
+}
+
 // Fast-forward along the unary path ahead of d.  Text byte 'pos' is the next
 // one to consume, at most 'limit' bytes may be consumed.  While the text
 // agrees with the single outgoing edge of each state, the walk goes
 // s -> s+1 -> ...; none of the states entered is final and depth grows in
 // step with the bytes consumed (an unmerged walk stays unmerged).  One load
-// level moves the walk up to 16 bytes.  Returns the bytes consumed.  (Stops
-// 20 bytes short of the padded end of the text: the caller single-steps there.)
+// level moves the walk up to 16 bytes.  (64 bytes per level -- four compares
+// in flight, always or only after a first full 16 -- was measured slower on
+// every percentile of the walk times, not just for short runs.)  Returns the
+// bytes consumed.  Stops 20 bytes short of the padded end of the text: the
+// caller single-steps there.
 template <class A>
 __device__ __forceinline__ uint32_t fast_forward(const A &a, Deep &d, uint32_t pos, uint32_t limit)
 {
 	uint32_t total = 0;
 	while (d.run != 0 && total < limit && pos + total + 20 <= a.n_pad) {
 		const uint32_t want = min(min(d.run, limit - total), 16u);
-		uint64_t x0, x1;
-		diff_bytes16(a.in_byte + d.s + 1, a.text + pos + total, x0, x1);
-		uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
-				   : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
-		same = min(same, want);
+		const uint32_t same = min(agree16(a.in_byte + d.s + 1, a.text + pos + total), want);
 		d.s += same;
 		d.depth += same;
 		d.run -= same;

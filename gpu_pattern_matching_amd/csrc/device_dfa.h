@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "acmatch.h"
@@ -16,12 +17,13 @@ struct acm_dfa {
 	uint32_t max_pattern_len = 0;
 
 	uint32_t *d_cold = nullptr;          // [states][256] target id
-	uint32_t *d_meta = nullptr;          // [states][256] depth(target) | run(target) << 16
+	uint64_t *d_deep = nullptr;          // [states][256] target id | depth(target) << 32 | run(target) << 48
 	uint16_t *d_hot = nullptr;           // [hot_rows][256]
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
-	uint8_t *d_in_byte = nullptr;        // [states + 32] byte on the edge into dev state
-	uint32_t *d_bloom = nullptr;         // [kBloomWords] trigrams of the depth-3 states (sparse pipeline)
+	uint8_t *d_in_byte = nullptr;        // [states + 96] byte on the edge into dev state
+	uint32_t *d_bloom = nullptr;         // [1 << bloom_log_words] trigrams of the depth-3 states (sparse pipeline)
+	uint32_t bloom_log_words = 15;
 	uint32_t *d_t2g = nullptr;           // [65536] state after bytes (p, c) from the root, index p | c << 8
 	size_t device_bytes = 0;
 
@@ -32,6 +34,28 @@ struct acm_dfa {
 
 	int chain_bytes = 0;                 // 0 = pick automatically
 	int chains_per_lane = 4;             // 2 or 4 independent chains per lane in the walk
+
+	// HIP graphs of batches that repeat (scan.hip, acm_scan_batch_async)
+	struct GraphKey {
+		const void *text;
+		size_t n, halo;
+		long offset_shift, init_state;
+		void *workspace;
+		size_t workspace_bytes;
+		void *pat_plane, *off_plane;
+		size_t plane_capacity;
+		int mode, chain_bytes, chains_per_lane;
+	};
+	struct GraphEntry {
+		GraphKey key;
+		void *exec;          // hipGraphExec_t, null until the key has been seen twice
+		uint64_t last_use;
+	};
+	static constexpr size_t kMaxGraphs = 32;
+	mutable bool use_graphs = false;     // opt-in: measured neutral on this stack
+	mutable std::vector<GraphEntry> graphs;
+	mutable std::mutex graph_mutex;
+	mutable uint64_t graph_tick = 0;
 
 	// optional in-line timing (acm_scan_profile_*): event triples
 	// {before walk, after walk, after last kernel} per recorded launch

@@ -9,10 +9,14 @@
 //   cold   u32 [states][256]    1 KiB rows, next state; "the transition is
 //                               final" is  next >= first_final  -- no flag
 //                               bits.  The walk kernel reads only this plane.
-//   meta   u32 [states][256]    depth(next) | run(next) << 16, same index: what
-//                               the boundary-resolve walks need about the state
-//                               they just entered (merge test, fast-forward)
-//                               comes back in the same load level as the state.
+//   deep   u64 [states][256]    next | depth(next) << 32 | run(next) << 48: what
+//                               the exact walks (boundary resolve, sparse
+//                               walkers) need about the state they enter
+//                               (merge test, fast-forward) comes back in the
+//                               same load as the state -- one load, one TLB
+//                               entry per step on a latency-bound path.  Costs
+//                               2 KiB per state next to the 1 KiB cold row;
+//                               HBM is not what this path is short of.
 //   hot    u16 [H][256]         rows of the first H (<= 256) non-final states
 //                               in BFS order (root, depth 1, ...): copied to
 //                               LDS by the walk kernel.  A cell holds the next
@@ -21,7 +25,7 @@
 //   out    i32 [states]         pattern index a final state reports (the head
 //                               of its match list, acsmx.c:650), -1 otherwise
 //   dev2ref u32 [states]        back to the reference's numbering (last_state)
-//   in_byte u8 [states + 32]    byte on the trie edge into each state; along
+//   in_byte u8 [states + 96]    byte on the trie edge into each state; along
 //                               a unary path the states ahead are d+1, d+2, ...
 //                               so 16 expected bytes are one contiguous load
 #include <hip/hip_runtime.h>
@@ -90,7 +94,7 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 			hot[i] = (uint16_t)((t < acm::kHotSentinel && t < F) ? t : acm::kHotSentinel);
 		}
 		std::vector<int32_t> outp(n);
-		std::vector<uint8_t> inb((size_t)n + 32, 0);
+		std::vector<uint8_t> inb((size_t)n + 96, 0);
 		for (uint32_t s = 0; s < n; s++) {
 			const uint32_t r = a->dev2ref[s];
 			outp[s] = a->is_final_ref(r) ? a->head_of(r) : -1;
@@ -101,10 +105,8 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 			for (size_t i = 0; i < rows.size(); i++)
 				plane[i] = (uint32_t)rows[i];
 			rc = upload(&d->d_cold, plane.data(), plane.size(), &d->device_bytes);
-			for (size_t i = 0; i < rows.size(); i++)
-				plane[i] = (uint32_t)(rows[i] >> 32);
 			if (rc == ACM_OK)
-				rc = upload(&d->d_meta, plane.data(), plane.size(), &d->device_bytes);
+				rc = upload(&d->d_deep, rows.data(), rows.size(), &d->device_bytes);
 		}
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_out, outp.data(), outp.size(), &d->device_bytes);
@@ -114,16 +116,26 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 
 		// sparse pipeline: Bloom filter over the byte triples that lead to a
 		// depth-3 state, and the depth <= 2 part of the DFA as a flat table
-		std::vector<uint32_t> bloom(acm::kBloomWords, 0), t2g(65536);
+		std::vector<uint32_t> tris, t2g(65536);
 		for (uint32_t s = 0; s < n; s++) {
 			const uint32_t r2 = a->dev2ref[s];
 			if (a->depth[r2] != 3)
 				continue;
 			const uint32_t r1 = a->parent[r2], r0 = a->parent[r1];
-			const uint32_t tri = (uint32_t)a->in_byte[r0] | ((uint32_t)a->in_byte[r1] << 8) |
-					     ((uint32_t)a->in_byte[r2] << 16);
-			bloom[acm::bloom_word(tri)] |= acm::bloom_bits(tri);
+			tris.push_back((uint32_t)a->in_byte[r0] | ((uint32_t)a->in_byte[r1] << 8) |
+			    ((uint32_t)a->in_byte[r2] << 16));
 		}
+		d->bloom_log_words = acm::kBloomMinLogWords;
+		while (d->bloom_log_words < acm::kBloomMaxLogWords && ((size_t)1 << d->bloom_log_words) < 4 * tris.size())
+			d->bloom_log_words++;
+		if (const char *e = getenv("ACM_BLOOM_LOG_WORDS")) {   // debugging aid
+			const int v = atoi(e);
+			if (v >= (int)acm::kBloomMinLogWords && v <= (int)acm::kBloomMaxLogWords)
+				d->bloom_log_words = (uint32_t)v;
+		}
+		std::vector<uint32_t> bloom((size_t)1 << d->bloom_log_words, 0);
+		for (uint32_t tri : tris)
+			bloom[acm::bloom_word(tri, d->bloom_log_words)] |= acm::bloom_bits(tri);
 		for (uint32_t p = 0; p < 256; p++) {
 			const uint32_t s1 = (uint32_t)rows[p];
 			for (uint32_t c = 0; c < 256; c++)
@@ -142,7 +154,7 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		acm_dfa_release(d);
 		return rc;
 	}
-	if (d->sparse_ok && acm::sparse_prepare(d) != ACM_OK) {
+	if (acm::scan_prepare(d) != ACM_OK || (d->sparse_ok && acm::sparse_prepare(d) != ACM_OK)) {
 		acm_dfa_release(d);
 		return ACM_ERR_HIP;
 	}
@@ -150,6 +162,8 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		if (!strcmp(m, "chain")) d->scan_mode = ACM_SCAN_MODE_CHAIN;
 		else if (!strcmp(m, "sparse")) d->scan_mode = ACM_SCAN_MODE_SPARSE;
 	}
+	if (const char *g = getenv("ACM_SCAN_GRAPHS"))
+		d->use_graphs = atoi(g) != 0;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess)
 		d->num_cus = prop.multiProcessorCount;
@@ -163,13 +177,16 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		return;
 	if (hipSetDevice(d->device) == hipSuccess) {
 		hipFree(d->d_cold);
-		hipFree(d->d_meta);
+		hipFree(d->d_deep);
 		hipFree(d->d_hot);
 		hipFree(d->d_out);
 		hipFree(d->d_dev2ref);
 		hipFree(d->d_in_byte);
 		hipFree(d->d_bloom);
 		hipFree(d->d_t2g);
+		for (auto &g : d->graphs)
+			if (g.exec)
+				hipGraphExecDestroy((hipGraphExec_t)g.exec);
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

@@ -39,8 +39,7 @@
 //                    up here, off the walk's critical path.
 //
 // Deep walks (K2) get everything about the state they enter with the state
-// itself: cold[idx] = state, meta[idx] = depth | run << 16 (same index, loaded
-// together).  depth feeds the merge
+// itself: deep[idx] = state | depth << 32 | run << 48.  depth feeds the merge
 // test; run is the length of the unary trie path ahead, along which states
 // are consecutive ids and the walk only compares text with in_byte[] --
 // 16 bytes per load level instead of one table lookup per byte.
@@ -50,6 +49,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include "acm_internal.h"
 #include "deep_walk.h"
@@ -72,7 +72,7 @@ constexpr uint8_t kProbeTodo = 0xFF;
 
 struct ScanArgs {
 	const uint32_t *cold;   // [states][256] next state
-	const uint32_t *meta;   // [states][256] depth(next) | run(next) << 16
+	const uint64_t *deep;   // [states][256] next | depth(next) << 32 | run(next) << 48
 	const uint16_t *hot;
 	const int32_t *out;
 	const uint32_t *dev2ref;
@@ -718,10 +718,7 @@ Layout layout_for(size_t max_text)
 template <int C>
 int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 {
-	const size_t lds = (size_t)a.H * 512;
-	if (lds > 48 * 1024)  // per device, so not cached in a static
-		ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_spec_walk<C>,
-		    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(acm::kHotRowsMax * 512)));
+	const size_t lds = (size_t)a.H * 512;   // above 48 KiB: allowed by acm::scan_prepare
 	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
 	if (blocks > (uint32_t)num_cus)
 		blocks = (uint32_t)num_cus;
@@ -820,10 +817,151 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	return acm_scan_batch_async(d, &b);
 }
 
+namespace acm {
+int scan_prepare(const acm_dfa *)
+{
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_spec_walk<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+	    (int)(acm::kHotRowsMax * 512)));
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_spec_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+	    (int)(acm::kHotRowsMax * 512)));
+	return ACM_OK;
+}
+}  // namespace acm
+
+namespace {
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch);
+
+// what a cached graph was captured for: every input of enqueue_batch except the stream
+acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b)
+{
+	acm_dfa::GraphKey k;
+	memset(&k, 0, sizeof(k));
+	k.text = b->d_text;
+	k.n = b->n;
+	k.halo = b->halo;
+	k.offset_shift = b->offset_shift;
+	k.init_state = b->init_state;
+	k.workspace = b->d_workspace;
+	k.workspace_bytes = b->workspace_bytes;
+	k.pat_plane = b->d_pat_plane;
+	k.off_plane = b->d_off_plane;
+	k.plane_capacity = b->plane_capacity;
+	k.mode = d->scan_mode;
+	k.chain_bytes = d->chain_bytes;
+	k.chains_per_lane = d->chains_per_lane;
+	return k;
+}
+}  // namespace
+
+// The kernels of one scan are short and many; a host that scans with the same
+// buffers over and over (a worker with its staging buffers, as the reference's
+// workers do) pays more for launching them than the GPU for running them.  So
+// the enqueue of a batch that repeats is captured once into a HIP graph and
+// replayed with one hipGraphLaunch.
 extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batch)
 {
 	if (!batch)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: null batch");
+	if (!d || !d->use_graphs || d->profile || !batch->stream || batch->wait_before_walk ||
+	    batch->record_after_walk || batch->n == 0)
+		return enqueue_batch(d, batch);
+	hipStream_t s = (hipStream_t)batch->stream;
+	const acm_dfa::GraphKey key = graph_key(d, batch);
+	hipGraphExec_t exec = nullptr;
+	bool capture = false;
+	{
+		std::lock_guard<std::mutex> lock(d->graph_mutex);
+		acm_dfa::GraphEntry *e = nullptr;
+		for (auto &g : d->graphs)
+			if (!memcmp(&g.key, &key, sizeof(key)))
+				e = &g;
+		if (!e) {   // first sighting: remember it, enqueue the plain way
+			if (d->graphs.size() >= acm_dfa::kMaxGraphs) {
+				size_t oldest = 0;
+				for (size_t i = 1; i < d->graphs.size(); i++)
+					if (d->graphs[i].last_use < d->graphs[oldest].last_use)
+						oldest = i;
+				if (d->graphs[oldest].exec)
+					hipGraphExecDestroy((hipGraphExec_t)d->graphs[oldest].exec);
+				d->graphs.erase(d->graphs.begin() + (long)oldest);
+			}
+			acm_dfa::GraphEntry fresh;
+			fresh.key = key;
+			fresh.exec = nullptr;
+			fresh.last_use = ++d->graph_tick;
+			d->graphs.push_back(fresh);
+		} else {
+			e->last_use = ++d->graph_tick;
+			exec = (hipGraphExec_t)e->exec;
+			capture = !exec;
+		}
+	}
+	if (exec) {
+		ACM_HIP_TRY(hipSetDevice(d->device));
+		ACM_HIP_TRY(hipGraphLaunch(exec, s));
+		return ACM_OK;
+	}
+	if (!capture)
+		return enqueue_batch(d, batch);
+	// second sighting: capture.  Argument errors surface here exactly as in the plain path.
+	ACM_HIP_TRY(hipSetDevice(d->device));
+	if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+		(void)hipGetLastError();
+		d->use_graphs = false;   // e.g. the caller is capturing this stream itself
+		return enqueue_batch(d, batch);
+	}
+	const int rc = enqueue_batch(d, batch);
+	hipGraph_t graph = nullptr;
+	const hipError_t end = hipStreamEndCapture(s, &graph);
+	if (rc != ACM_OK || end != hipSuccess || !graph) {
+		if (graph)
+			hipGraphDestroy(graph);
+		(void)hipGetLastError();
+		d->use_graphs = false;
+		return rc != ACM_OK ? rc : enqueue_batch(d, batch);
+	}
+	const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+	hipGraphDestroy(graph);
+	if (inst != hipSuccess || !exec) {
+		(void)hipGetLastError();
+		d->use_graphs = false;
+		return enqueue_batch(d, batch);
+	}
+	{
+		std::lock_guard<std::mutex> lock(d->graph_mutex);
+		bool stored = false;
+		for (auto &g : d->graphs)
+			if (!memcmp(&g.key, &key, sizeof(key)) && !g.exec) {
+				g.exec = (void *)exec;
+				stored = true;
+			}
+		if (!stored) {   // evicted, or another thread was quicker
+			ACM_HIP_TRY(hipGraphLaunch(exec, s));
+			// cannot destroy while in flight: park it in the list under a key nobody asks for
+			acm_dfa::GraphEntry parked;
+			memset(&parked.key, 0xFF, sizeof(parked.key));
+			parked.exec = (void *)exec;
+			parked.last_use = 0;
+			d->graphs.push_back(parked);
+			return ACM_OK;
+		}
+	}
+	ACM_HIP_TRY(hipGraphLaunch(exec, s));
+	return ACM_OK;
+}
+
+extern "C" int acm_scan_set_graphs(acm_dfa *d, int enable)
+{
+	if (!d)
+		return 0;
+	if (enable >= 0)
+		d->use_graphs = enable != 0;
+	return d->use_graphs ? 1 : 0;
+}
+
+namespace {
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
+{
 	const void *d_text = batch->d_text;
 	const size_t n = batch->n, halo = batch->halo;
 	const long offset_shift = batch->offset_shift, init_state = batch->init_state;
@@ -870,7 +1008,7 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 	ScanArgs a;
 	memset(&a, 0, sizeof(a));
 	a.cold = d->d_cold;
-	a.meta = d->d_meta;
+	a.deep = d->d_deep;
 	a.hot = d->d_hot;
 	a.out = d->d_out;
 	a.dev2ref = d->d_dev2ref;
@@ -975,6 +1113,8 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 	}
 	return ACM_OK;
 }
+
+}  // namespace
 
 extern "C" int acm_scan_profile_enable(acm_dfa *d, int enable)
 {

@@ -15,7 +15,8 @@ namespace acm {
 // bytes of private workspace the sparse pipeline needs for texts up to max_text
 size_t sparse_workspace_bytes(size_t max_text);
 
-// once per device DFA: kernel attributes
+// once per device DFA: kernel attributes (scan.hip / sparse.hip)
+int scan_prepare(const acm_dfa *d);
 int sparse_prepare(const acm_dfa *d);
 
 // Enqueue the sparse pipeline for 'b' on stream s.  *gate = device word that is

@@ -19,7 +19,7 @@
 //                         Output: one candidate bit per text byte.
 //   SW  k_sparse_walk     one walker per run of consecutive candidate bits:
 //                         start in T2[bytes a-2, a-1] at position a and walk
-//                         the DFA exactly (cold/meta planes, fast-forward)
+//                         the DFA exactly (deep plane, fast-forward)
 //                         while the state is deep or the next position is a
 //                         candidate.  A walker that started while an earlier
 //                         deep run was still alive walks suffix-states of the
@@ -44,7 +44,7 @@
 //
 // The state carried into the buffer (init_state) is handled by a walker at
 // position 0 that starts from it.  Work is capped -- table steps per walker,
-// walkers per 4096 positions, hits per 16384 positions; texts beyond the caps
+// walkers per 8192 positions, hits per 32768 positions; texts beyond the caps
 // (one endless deep run, a match at every byte) raise a device flag and the
 // chain pipeline, enqueued right behind and otherwise a row of early-exit
 // launches, produces the planes instead.
@@ -52,6 +52,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "acm_internal.h"
@@ -61,26 +62,30 @@
 
 namespace {
 
-using acm::kBloomWords;
 using acm_dev::ChainText;
 using acm_dev::Deep;
 using acm_dev::deep_step;
 using acm_dev::fast_forward;
 
 constexpr int kFilterBlock = 1024;
-constexpr int kWordBlock = 256;            // words (of 64 text positions) per SE workgroup
-constexpr int kWordWaves = kWordBlock / 64;
+constexpr int kWalkBlock = 256;            // threads of a SW workgroup
+constexpr int kWalkWaves = kWalkBlock / 64;
+constexpr uint32_t kLaneWords = 2;         // words (of 64 text positions) per lane (1, 2, 4 measured: 2 is best) ...
+constexpr uint32_t kWaveWords = 64 * kLaneWords;             // ... per wave: 8192 positions
+constexpr uint32_t kBlockWords = kWalkWaves * kWaveWords;    // ... per workgroup: 32768 positions
 constexpr uint32_t kIterCap = 256;         // table steps one walker may take ...
 constexpr uint32_t kForwardCap = 4096;     // ... each followed by this many fast-forwarded bytes at most
-constexpr uint32_t kMaxWalkWave = 128;     // walkers per wave (4096 positions)
-constexpr uint32_t kMaxHits = 128;         // staged hits per workgroup (16384 positions)
+constexpr uint32_t kMaxWalkWave = 256;     // walkers per wave (8192 positions)
+constexpr uint32_t kMaxHits = 256;         // staged hits per workgroup (32768 positions)
 
 struct SparseArgs {
-	const uint32_t *cold, *meta;
+	const uint32_t *cold;
+	const uint64_t *deep;     // [states][256] next | depth(next) << 32 | run(next) << 48
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	const uint8_t *in_byte;
-	const uint32_t *bloom;    // [kBloomWords] blocked Bloom filter of the depth-3 trigrams
+	const uint32_t *bloom;    // [bloom_words] blocked Bloom filter of the depth-3 trigrams
+	uint32_t bloom_words, bloom_log_words;
 	const uint32_t *t2g;      // [65536] state after bytes (p, c) from the root, index p | c << 8
 	const uint4 *text16;
 	const uint8_t *text;
@@ -94,7 +99,7 @@ struct SparseArgs {
 	uint16_t *mask;                // [n_pad / 16 + 8] candidate bits
 	uint32_t *block_extent;        // [nblocks] largest deep extent + 1 of the workgroup's walkers
 	uint32_t *block_hits;          // [nblocks] hits the workgroup staged
-	uint2 *hit_list;               // [nblocks][kMaxHits] {position, state}, ascending positions
+	uint2 *hit_list;               // [nblocks][kMaxHits] {position, pattern}, ascending positions
 	uint32_t *flags;               // [0] gave up -> chain pipeline runs
 	unsigned long long *keeper;    // start position << 32 | state of the first walker that reached the end
 	// output
@@ -105,32 +110,33 @@ struct SparseArgs {
 // ------------------------------------------------------------------ SF ---
 
 // bit 0 of the result: both filter bits of the trigram (low 24 bits of tri) are set
-__device__ __forceinline__ uint32_t bloom_test(const uint32_t *bloom, uint32_t tri)
+__device__ __forceinline__ uint32_t bloom_test(const uint32_t *bloom, uint32_t tri, uint32_t word_shift)
 {
 	const uint32_t p1 = __umul24(tri, acm::kBloomMul1), p2 = __umul24(tri, acm::kBloomMul2);
-	const uint32_t w = bloom[p1 >> (32 - acm::kBloomLogWords)];
+	const uint32_t w = bloom[p1 >> word_shift];
 	return (w >> (p2 >> 27)) & (w >> ((p2 >> 22) & 31));
 }
 
 // shifts the candidate bit of position K of the 16-byte group into m from the top
 template <int K>
-__device__ __forceinline__ uint32_t probe(const uint32_t *bloom, const uint32_t (&x)[5], uint32_t m)
+__device__ __forceinline__ uint32_t probe(const uint32_t *bloom, uint32_t word_shift, const uint32_t (&x)[5],
+    uint32_t m)
 {
 	// bytes (K-2, K-1, K) of the group; x[0] is the dword in front of it
 	constexpr int lo = (K + 2) / 4, sh = (K + 2) % 4;
 	const uint32_t v = sh == 0 ? x[lo] : __builtin_amdgcn_alignbyte(x[lo + 1 > 4 ? 4 : lo + 1], x[lo], sh);
-	return __builtin_amdgcn_alignbit(bloom_test(bloom, v), m, 1);
+	return __builtin_amdgcn_alignbit(bloom_test(bloom, v, word_shift), m, 1);
 }
 
-// persistent: one workgroup per CU keeps the filter in LDS; a wave-iteration
-// reads 1 KiB of text with one coalesced 16 B/lane load
+// persistent workgroups keep the filter in LDS; a wave-iteration reads 1 KiB of
+// text with one coalesced 16 B/lane load, issued one iteration ahead of its use
 __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
 	{
 		const uint4 *src = (const uint4 *)a.bloom;
 		uint4 *dst = (uint4 *)bloom;
-		constexpr uint32_t n16 = kBloomWords / 4;
+		const uint32_t n16 = a.bloom_words / 4;
 		const uint32_t rot = (blockIdx.x * 1021u) % n16;
 		for (uint32_t i = threadIdx.x; i < n16; i += kFilterBlock) {
 			uint32_t j = i + rot;
@@ -143,25 +149,40 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 		*a.keeper = ~0ull;
 	}
 	__syncthreads();
+	const uint32_t word_shift = 32 - a.bloom_log_words;
 	const uint32_t n16 = a.n_pad >> 4;
 	const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * (kFilterBlock / 64) + (threadIdx.x >> 6);
 	const uint32_t nw = gridDim.x * (kFilterBlock / 64);
 	const uint32_t *text32 = (const uint32_t *)a.text16;
-	for (uint32_t t = wave; t * 64 < n16 + 8; t += nw) {
+	const uint32_t tiles = (n16 + 8 + 63) / 64;   // wave-iterations, including the 8 padding cells
+	uint4 w = make_uint4(0, 0, 0, 0);
+	uint32_t prev = 0;
+	if (wave < tiles && wave * 64 + lane < n16) {
+		w = a.text16[wave * 64 + lane];
+		prev = wave * 64 + lane ? text32[(wave * 64 + lane) * 4 - 1] : 0u;
+	}
+	for (uint32_t t = wave; t < tiles; t += nw) {
 		const uint32_t i16 = t * 64 + lane;
+		const uint32_t x[5] = { prev, w.x, w.y, w.z, w.w };
+		const uint32_t i16n = (t + nw) * 64 + lane;   // next iteration's group: load now, use then
+		if (t + nw < tiles && i16n < n16) {
+			w = a.text16[i16n];
+			prev = text32[i16n * 4 - 1];
+		}
 		if (i16 >= n16) {
 			if (i16 < n16 + 8)
 				a.mask[i16] = 0;   // padding the walkers may read
 			continue;
 		}
-		const uint4 w = a.text16[i16];
-		const uint32_t prev = i16 ? text32[i16 * 4 - 1] : 0u;
-		const uint32_t x[5] = { prev, w.x, w.y, w.z, w.w };
 		uint32_t m = 0;
-		m = probe<0>(bloom, x, m); m = probe<1>(bloom, x, m); m = probe<2>(bloom, x, m); m = probe<3>(bloom, x, m);
-		m = probe<4>(bloom, x, m); m = probe<5>(bloom, x, m); m = probe<6>(bloom, x, m); m = probe<7>(bloom, x, m);
-		m = probe<8>(bloom, x, m); m = probe<9>(bloom, x, m); m = probe<10>(bloom, x, m); m = probe<11>(bloom, x, m);
-		m = probe<12>(bloom, x, m); m = probe<13>(bloom, x, m); m = probe<14>(bloom, x, m); m = probe<15>(bloom, x, m);
+		m = probe<0>(bloom, word_shift, x, m); m = probe<1>(bloom, word_shift, x, m);
+		m = probe<2>(bloom, word_shift, x, m); m = probe<3>(bloom, word_shift, x, m);
+		m = probe<4>(bloom, word_shift, x, m); m = probe<5>(bloom, word_shift, x, m);
+		m = probe<6>(bloom, word_shift, x, m); m = probe<7>(bloom, word_shift, x, m);
+		m = probe<8>(bloom, word_shift, x, m); m = probe<9>(bloom, word_shift, x, m);
+		m = probe<10>(bloom, word_shift, x, m); m = probe<11>(bloom, word_shift, x, m);
+		m = probe<12>(bloom, word_shift, x, m); m = probe<13>(bloom, word_shift, x, m);
+		m = probe<14>(bloom, word_shift, x, m); m = probe<15>(bloom, word_shift, x, m);
 		m >>= 16;
 		if (i16 == 0)
 			m &= ~3u;                        // no full trigram yet: the position-0 walker covers these
@@ -233,9 +254,9 @@ __device__ __forceinline__ bool walker(const SparseArgs &a, HitList &hits, const
 				reached_end = true;
 				break;
 			}
-			// candidate bit of position p: in LDS for the wave's own 4096 positions
+			// candidate bit of position p: in LDS for the wave's own positions
 			const uint32_t wi = (p >> 6) - word0;
-			const uint64_t mbits = wi < 64 ? lmask[wi] : *(const uint64_t *)(a.mask + (size_t)(p >> 6) * 4);
+			const uint64_t mbits = wi < kWaveWords ? lmask[wi] : *(const uint64_t *)(a.mask + (size_t)(p >> 6) * 4);
 			if (!((mbits >> (p & 63)) & 1ull))
 				break;
 		}
@@ -250,12 +271,12 @@ __device__ __forceinline__ bool walker(const SparseArgs &a, HitList &hits, const
 	return ok;
 }
 
-__global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
+__global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 {
 	__shared__ HitList hits;
-	__shared__ uint64_t lmask[kWordWaves][64];               // candidate bits of the wave's words
-	__shared__ int32_t walker_m[kWordWaves][kMaxWalkWave];   // max deep extent of the wave's walkers before k
-	__shared__ int32_t wave_max[kWordWaves];
+	__shared__ uint64_t lmask[kWalkWaves][kWaveWords];       // candidate bits of the wave's words
+	__shared__ int32_t walker_m[kWalkWaves][kMaxWalkWave];   // max deep extent of the wave's walkers before k
+	__shared__ int32_t wave_max[kWalkWaves];
 	__shared__ uint32_t s_gave_up, s_survivors;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	if (threadIdx.x == 0) {
@@ -264,19 +285,28 @@ __global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 		s_survivors = 0;
 	}
 	__syncthreads();
-	const uint32_t w = blockIdx.x * kWordBlock + threadIdx.x;
+	// a lane owns kLaneWords consecutive words, a wave kWaveWords
+	const uint32_t word0 = (blockIdx.x * kWalkWaves + wv) * kWaveWords;   // the wave's first word
+	const uint32_t w = word0 + lane * kLaneWords;                          // the lane's first word
 
-	// the walkers of this wave's 64 words (4096 positions), in position order
-	uint64_t starts = 0, m = 0;
-	if (w < a.nwords) {
-		m = *(const uint64_t *)(a.mask + (size_t)w * 4);
-		const uint64_t prev = w ? (uint64_t)(a.mask[(size_t)w * 4 - 1] >> 15) : 0ull;
-		starts = m & ~((m << 1) | prev);   // first bit of every run of candidate bits
+	// the walkers of the wave, in position order
+	uint64_t starts[kLaneWords];
+	uint32_t cnt = 0;
+	{
+		uint64_t prev = (w && w < a.nwords) ? (uint64_t)(a.mask[(size_t)w * 4 - 1] >> 15) : 0ull;
+#pragma unroll
+		for (uint32_t j = 0; j < kLaneWords; j++) {
+			const uint64_t m = w + j < a.nwords ? *(const uint64_t *)(a.mask + (size_t)(w + j) * 4) : 0ull;
+			starts[j] = m & ~((m << 1) | prev);   // first bit of every run of candidate bits
+			prev = m >> 63;
+			lmask[wv][lane * kLaneWords + j] = m;
+		}
 		if (w == 0)
-			starts |= 1ull;                // the walker that carries init_state (bits 0, 1 are never candidates)
+			starts[0] |= 1ull;   // the walker that carries init_state (bits 0, 1 are never candidates)
+#pragma unroll
+		for (uint32_t j = 0; j < kLaneWords; j++)
+			cnt += (uint32_t)__popcll(starts[j]);
 	}
-	lmask[wv][lane] = m;
-	const uint32_t cnt = (uint32_t)__popcll(starts);
 	uint32_t inc = cnt;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
@@ -299,16 +329,33 @@ __global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 			if (cand < 64 && b <= k)
 				owner_lane = cand;
 		}
-		const uint32_t lo = __shfl((uint32_t)starts, owner_lane, 64);
-		const uint32_t hi = __shfl((uint32_t)(starts >> 32), owner_lane, 64);
-		const uint32_t first = __shfl(base, owner_lane, 64);
+		uint32_t skip = k - __shfl(base, owner_lane, 64);   // walkers of the owner lane in front of k
+		uint64_t word_starts = 0;                            // start bits of the word walker k is in
+		uint32_t word_index = 0;
+		bool found = false;
+#pragma unroll
+		for (uint32_t j = 0; j < kLaneWords; j++) {
+			const uint32_t lo = __shfl((uint32_t)starts[j], owner_lane, 64);
+			const uint32_t hi = __shfl((uint32_t)(starts[j] >> 32), owner_lane, 64);
+			const uint64_t sj = ((uint64_t)hi << 32) | lo;
+			const uint32_t c = (uint32_t)__popcll(sj);
+			if (!found) {
+				if (skip < c) {
+					word_starts = sj;
+					word_index = j;
+					found = true;
+				} else {
+					skip -= c;
+				}
+			}
+		}
 		int32_t end = -1;
 		if (valid) {
-			uint64_t s = ((uint64_t)hi << 32) | lo;
-			for (uint32_t i = first; i < k; i++)
-				s &= s - 1;
-			const uint32_t p0 = ((w - lane + owner_lane) << 6) + (uint32_t)__ffsll((long long)s) - 1;
-			ok &= walker(a, hits, lmask[wv], w - lane, (wv << 16) | k, p0, end);
+			for (uint32_t i = 0; i < skip; i++)
+				word_starts &= word_starts - 1;
+			const uint32_t p0 = ((word0 + owner_lane * kLaneWords + word_index) << 6) +
+					    (uint32_t)__ffsll((long long)word_starts) - 1;
+			ok &= walker(a, hits, lmask[wv], word0, (wv << 16) | k, p0, end);
 		}
 		int32_t incm = end;   // inclusive prefix max over the round, then exclusive + earlier rounds
 #pragma unroll
@@ -332,7 +379,7 @@ __global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 
 	// drop the hits an earlier walker of this workgroup covers
 	const uint32_t nh = min(hits.count, kMaxHits);
-	for (uint32_t i = threadIdx.x; i < nh; i += kWordBlock) {
+	for (uint32_t i = threadIdx.x; i < nh; i += kWalkBlock) {
 		const uint32_t o = hits.owner[i], ow = o >> 16;
 		int32_t m = walker_m[ow][o & 0xFFFFu];
 		for (uint32_t v = 0; v < ow; v++)
@@ -343,14 +390,14 @@ __global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 	__syncthreads();
 	// the others have distinct positions: rank = number of survivors in front
 	uint32_t survivors = 0;
-	for (uint32_t i = threadIdx.x; i < nh; i += kWordBlock) {
+	for (uint32_t i = threadIdx.x; i < nh; i += kWalkBlock) {
 		if (hits.owner[i] & 0x80000000u)
 			continue;
 		const uint32_t pos = hits.pos[i];
 		uint32_t rank = 0;
 		for (uint32_t j = 0; j < nh; j++)
 			rank += (!(hits.owner[j] & 0x80000000u) && hits.pos[j] < pos) ? 1u : 0u;
-		a.hit_list[(size_t)blockIdx.x * kMaxHits + rank] = make_uint2(pos, hits.state[i]);
+		a.hit_list[(size_t)blockIdx.x * kMaxHits + rank] = make_uint2(pos, (uint32_t)a.out[hits.state[i]]);
 		survivors++;
 	}
 #pragma unroll
@@ -361,7 +408,7 @@ __global__ __launch_bounds__(kWordBlock, 8) void k_sparse_walk(SparseArgs a)
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		int32_t bm = -1;
-		for (int i = 0; i < kWordWaves; i++)
+		for (int i = 0; i < kWalkWaves; i++)
 			bm = max(bm, wave_max[i]);
 		a.block_extent[blockIdx.x] = (uint32_t)(bm + 1);
 		a.block_hits[blockIdx.x] = s_survivors;
@@ -405,6 +452,8 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 __global__ __launch_bounds__(kEmitBlock) void k_sparse_emit(SparseArgs a)
 {
 	__shared__ uint32_t lds[kEmitBlock / 64];
+	__shared__ uint32_t first_cell[kEmitBlock + 1];   // output cell of each workgroup's first kept hit (this pass)
+	__shared__ uint32_t first_kept[kEmitBlock];       // index of that hit in the workgroup's list
 	if (a.flags[0])
 		return;   // a cap was hit: the chain pipeline behind this kernel produces the planes
 	uint32_t extent_before = 0, cells_before = 0;   // over the workgroups of earlier passes
@@ -413,22 +462,44 @@ __global__ __launch_bounds__(kEmitBlock) void k_sparse_emit(SparseArgs a)
 		const bool live = b < a.nblocks;
 		const uint32_t extent = live ? a.block_extent[b] : 0u;
 		const uint32_t staged = live ? a.block_hits[b] : 0u;
+		const uint2 *list = a.hit_list + (size_t)b * kMaxHits;
+		// the list is sorted: what an earlier workgroup's walker covers is a prefix of it.  Its first
+		// entries are fetched before 'covered' is known (one load level instead of a dependent loop)
+		uint2 head[4];
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++)
+			head[i] = i < staged ? list[i] : make_uint2(0xFFFFFFFFu, 0u);
 		uint32_t pass_extent, pass_cells;
 		const uint32_t covered = max(extent_before, block_exclusive<true>(extent, lds, &pass_extent));
-		// the list is sorted: what an earlier workgroup's walker covers is a prefix of it
-		const uint2 *list = a.hit_list + (size_t)b * kMaxHits;
 		uint32_t dropped = 0;
-		while (dropped < staged && list[dropped].x < covered)
-			dropped++;
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++)
+			dropped += (i < staged && head[i].x < covered) ? 1u : 0u;
+		if (dropped == 4)
+			while (dropped < staged && list[dropped].x < covered)
+				dropped++;
 		const uint32_t kept = staged - dropped;
-		uint32_t d = cells_before + block_exclusive<false>(kept, lds, &pass_cells);
-		for (uint32_t i = dropped; i < staged; i++, d++) {
-			const uint2 rec = list[i];
+		const uint32_t cell = block_exclusive<false>(kept, lds, &pass_cells);
+		first_cell[threadIdx.x] = cell;
+		first_kept[threadIdx.x] = dropped;
+		if (threadIdx.x == 0)
+			first_cell[kEmitBlock] = pass_cells;
+		__syncthreads();
+		// one thread per output cell: find the workgroup it belongs to, copy the record
+		for (uint32_t c = threadIdx.x; c < pass_cells; c += kEmitBlock) {
+			uint32_t lo = 0;   // last workgroup whose first cell is <= c (those without hits share a cell with the next)
+#pragma unroll
+			for (uint32_t step = kEmitBlock / 2; step > 0; step >>= 1)
+				if (first_cell[lo + step] <= c)
+					lo += step;
+			const uint2 rec = a.hit_list[(size_t)(first + lo) * kMaxHits + first_kept[lo] + (c - first_cell[lo])];
+			const uint32_t d = cells_before + c;
 			if (d + 2 < a.plane_capacity) {
-				a.pat_plane[1 + d] = a.out[rec.y];
+				a.pat_plane[1 + d] = (int32_t)rec.y;
 				a.off_plane[1 + d] = (int32_t)rec.x + a.off_shift;
 			}
 		}
+		__syncthreads();
 		extent_before = max(extent_before, pass_extent);
 		cells_before += pass_cells;
 	}
@@ -459,7 +530,7 @@ namespace acm {
 
 size_t sparse_workspace_bytes(size_t max_text)
 {
-	const size_t blocks = (max_text / 64 + 2) / kWordBlock + 2;
+	const size_t blocks = (max_text / 64 + 2) / kBlockWords + 2;
 	size_t o = 0;
 	o += align_up((max_text / 16 + 16) * 2, 256);   // mask
 	o += align_up(blocks * 4, 256) * 2;              // per-workgroup extent, hit count
@@ -471,7 +542,7 @@ size_t sparse_workspace_bytes(size_t max_text)
 int sparse_prepare(const acm_dfa *)
 {
 	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sparse_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
-	    (int)(kBloomWords * 4)));
+	    (int)(acm::kBloomMaxWords * 4)));
 	return ACM_OK;
 }
 
@@ -482,11 +553,13 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	SparseArgs a;
 	memset(&a, 0, sizeof(a));
 	a.cold = d->d_cold;
-	a.meta = d->d_meta;
+	a.deep = d->d_deep;
 	a.out = d->d_out;
 	a.dev2ref = d->d_dev2ref;
 	a.in_byte = d->d_in_byte;
 	a.bloom = d->d_bloom;
+	a.bloom_log_words = d->bloom_log_words;
+	a.bloom_words = 1u << d->bloom_log_words;
 	a.t2g = d->d_t2g;
 	a.text16 = (const uint4 *)b->d_text;
 	a.text = (const uint8_t *)b->d_text;
@@ -497,7 +570,7 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	a.drop_before = (uint32_t)b->halo;
 	a.off_shift = (int32_t)b->offset_shift;
 	a.nwords = (uint32_t)((n + 63) / 64);
-	a.nblocks = (a.nwords + kWordBlock - 1) / kWordBlock;
+	a.nblocks = (a.nwords + kBlockWords - 1) / kBlockWords;
 	char *ws = (char *)sparse_ws;
 	size_t o = 0;
 	auto take = [&](size_t bytes) {
@@ -505,7 +578,7 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		o += align_up(bytes, 256);
 		return p;
 	};
-	const size_t blocks = (n / 64 + 2) / kWordBlock + 2;
+	const size_t blocks = (n / 64 + 2) / kBlockWords + 2;
 	a.mask = (uint16_t *)take((n / 16 + 16) * 2);
 	a.block_extent = (uint32_t *)take(blocks * 4);
 	a.block_hits = (uint32_t *)take(blocks * 4);
@@ -517,15 +590,17 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	a.plane_capacity = (uint32_t)(b->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : b->plane_capacity);
 	*gate = a.flags;
 
-	const size_t lds = (size_t)kBloomWords * 4;
+	// a small filter leaves room for two workgroups per CU (and for the other kernels' LDS)
+	const size_t lds = (size_t)a.bloom_words * 4;
+	const uint32_t per_cu = lds <= 64 * 1024 ? 2 : 1;
 	const uint32_t wave_iters = (a.n_pad / 16 + 8 + 63) / 64;
 	uint32_t fblocks = (wave_iters + kFilterBlock / 64 - 1) / (kFilterBlock / 64);
-	if (fblocks > (uint32_t)d->num_cus)
-		fblocks = (uint32_t)d->num_cus;
+	if (fblocks > (uint32_t)d->num_cus * per_cu)
+		fblocks = (uint32_t)d->num_cus * per_cu;
 	hipLaunchKernelGGL(k_sparse_filter, dim3(fblocks), dim3(kFilterBlock), lds, s, a);
 	if (after_filter)
 		ACM_HIP_TRY(hipEventRecord(after_filter, s));
-	hipLaunchKernelGGL(k_sparse_walk, dim3(a.nblocks), dim3(kWordBlock), 0, s, a);
+	hipLaunchKernelGGL(k_sparse_walk, dim3(a.nblocks), dim3(kWalkBlock), 0, s, a);
 	if (after_walk)
 		ACM_HIP_TRY(hipEventRecord(after_walk, s));
 	hipLaunchKernelGGL(k_sparse_emit, dim3(1), dim3(kEmitBlock), 0, s, a);

@@ -194,6 +194,16 @@ int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
 /* number of kernels one acm_scan_async enqueues for a non-empty text (chain pipeline) */
 int acm_scan_kernel_count(void);
 
+/* A scan whose arguments repeat (same text buffer, size, workspace, planes,
+ * init_state ... -- a worker cycling through its staging buffers) is captured
+ * into a HIP graph the second time it is seen and replayed from then on: one
+ * hipGraphLaunch instead of a row of kernel launches.  Off by default (on
+ * MI355X / ROCm 7.2 it saves a few microseconds of host time per scan and
+ * nothing on the GPU); never used with the NULL stream, profiling or the
+ * event fields of acm_scan_batch.  enable = 0 / 1, -1 only queries.  Returns
+ * the setting in use. */
+int acm_scan_set_graphs(acm_dfa *, int enable);
+
 /* Which pipeline acm_scan_*_async runs.  Both produce the same planes.
  *   CHAIN   speculative chains (any pattern set)
  *   SPARSE  trigram filter + candidate walks; needs every pattern to have

@@ -12,6 +12,7 @@ import pytest
 import fixtures
 import orc
 from gpu_pattern_matching_amd import AcmError, Automaton, DeviceArray, Matcher
+from gpu_pattern_matching_amd._lib import check
 
 pytestmark = pytest.mark.gpu
 
@@ -208,3 +209,30 @@ def test_bad_arguments(gpu, lib):
     with pytest.raises(AcmError):
         m.scan_async(d.ptr + 1, 16)                    # misaligned text
     d.free()
+
+
+@pytest.mark.parametrize("mode", ["chain", "auto"])
+def test_graph_replay_tracks_buffer_contents(gpu, mode):
+    """With acm_scan_set_graphs on, a scan that repeats with the same buffers is replayed as a HIP
+    graph from its third enqueue on: the replay reads what is in the buffers then, not what
+    was there at capture, and gives what separate launches give."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    m = matcher_for(name, max_text=1 << 20)
+    m.set_mode(mode)
+    n = 1 << 20
+    d = DeviceArray(n)
+    try:
+        for graphs in (True, False):
+            assert m.set_graphs(graphs) == graphs
+            for seed in range(5):
+                text = fixtures.text_for({"kind": "clamav", "n": n, "seed": 40 + seed, "n_plant": 100 * seed},
+                                         pats)
+                check(m.lib.acm_rt_memcpy_h2d(d.ptr, text.ctypes.data, n, m.stream), "h2d")
+                m.scan_async(d, n)
+                assert_same(m.fetch(), o.scan(text))
+    finally:
+        m.set_graphs(False)
+        m.set_mode("auto")
+        d.free()
