@@ -294,17 +294,19 @@ def main():
                        "all_cores": {"value": round(SHARD / t_all / 1e9, 4), "cores": ncpu}}
             o.close()
 
-        # the kernel the roofline is quoted for: the longest one of the pipeline that ran.
-        # chain: k_spec_walk reads the text once and stages 8 B per record.  sparse: k_sparse_filter
-        # reads the text once and writes one candidate bit per byte; k_sparse_walk reads those bits
-        # and stages 8 B per record (it is latency bound: a few thousand dependent table walks).
+        # The roofline is quoted for the longest kernel of the pipeline that ran.  Every kernel of a
+        # pipeline is a stage over the same N text positions, so the units one launch processes are
+        # the N bytes of the batch and the algorithmic bytes are SURVEY 8(d)'s per-scan figure,
+        # N x 1 B of text + 8 B per record, whichever stage is the slowest (chain: k_spec_walk reads
+        # the text; sparse: k_sparse_filter reads the text and hands one candidate bit per byte to
+        # k_sparse_walk, which is latency bound on a few ten thousand dependent table walks).
         L1 = max(launches, 1)
+        alg_bytes = n_local + 8 * m_local
         if path == "chain":
-            kernels = [("k_spec_walk", k1_ms, solo_k1_ms, n_local + 8 * m_local)]
+            kernels = [("k_spec_walk", k1_ms, solo_k1_ms)]
         else:
-            kernels = [("k_sparse_filter", k1_ms, solo_k1_ms, n_local + n_local // 8),
-                       ("k_sparse_walk", k2_ms, solo_k2_ms, n_local // 8 + 8 * m_local)]
-        kname, kms, ksolo_ms, alg_bytes = max(kernels, key=lambda t: t[1])
+            kernels = [("k_sparse_filter", k1_ms, solo_k1_ms), ("k_sparse_walk", k2_ms, solo_k2_ms)]
+        kname, kms, ksolo_ms = max(kernels, key=lambda t: t[1])
         walk_s = kms / 1e3 / L1
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         value = total_bytes * args.steps / elapsed / 1e9
@@ -312,11 +314,14 @@ def main():
         # (tests/run_pmc.sh -> tests/pmc_summarize.py -> profiles/r1_traffic.json); counters
         # cannot be collected inside a timed run, so this is read back, never estimated
         traffic = None
+        stage_traffic = {}
         tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tfile) and args.sigs == 2000 and args.max_len < 0:
             for name, rec in json.load(open(tfile)).items():
-                if kname in name:
-                    traffic = round(rec["hbm_bytes_per_launch"], 1)
+                for k in kernels:
+                    if k[0] in name:
+                        stage_traffic[k[0]] = round(rec["hbm_bytes_per_launch"], 1)
+            traffic = stage_traffic.get(kname)
         out = {
             "metric": "input_GB_per_s_scanned",
             "value": round(value, 3),
@@ -362,6 +367,10 @@ def main():
                 "kernel_us": round(walk_s * 1e6, 2),
                 "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
                 "kernels_us": {k[0]: round(k[1] / L1 * 1e3, 2) for k in kernels},
+                "stages": [{"kernel": k[0], "us": round(k[1] / L1 * 1e3, 2),
+                            "achieved": round(alg_bytes / (k[1] / 1e3 / L1) / 1e9, 1) if k[1] > 0 else None,
+                            "frac": round(alg_bytes / (k[1] / 1e3 / L1) / 1e9 / HBM_PEAK_GBS, 4) if k[1] > 0 else None,
+                            "traffic": stage_traffic.get(k[0])} for k in kernels],
                 "launches_timed": launches,
                 "note": "HIP events on the batch's own stream around the kernels of every %d-th step of the "
                         "timed region; with %d batches in flight a kernel shares the GPU with the other "
