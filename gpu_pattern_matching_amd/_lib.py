@@ -23,7 +23,10 @@ class ScanBatch(C.Structure):
     _fields_ = [("d_text", _vp), ("n", C.c_size_t), ("halo", C.c_size_t), ("offset_shift", C.c_long),
                 ("init_state", C.c_long), ("d_workspace", _vp), ("workspace_bytes", C.c_size_t),
                 ("d_pat_plane", _vp), ("d_off_plane", _vp), ("plane_capacity", C.c_size_t),
-                ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp)]
+                ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp), ("report", C.c_int)]
+
+
+REPORT_HEAD, REPORT_STATE = 0, 1
 
 
 class AcmError(RuntimeError):
@@ -40,6 +43,7 @@ NATIVE_API = {
     "acm_version": (C.c_char_p, []),
     "acm_device_count": (C.c_int, []),
     "acm_automaton_new": (_vp, []),
+    "acm_automaton_state_matches": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "acm_automaton_free": (None, [_vp]),
     "acm_automaton_add": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "acm_automaton_load_file": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
@@ -65,6 +69,8 @@ NATIVE_API = {
     "acm_scan_set_chain_bytes": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_chains_per_lane": (C.c_int, [_vp, C.c_int]),
     "acm_scan_kernel_count": (C.c_int, []),
+    "acm_expand_workspace_bytes": (C.c_size_t, [C.c_size_t]),
+    "acm_expand_matches_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "acm_scan_set_mode": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_graphs": (C.c_int, [_vp, C.c_int]),
     "acm_scan_sparse_eligible": (C.c_int, [_vp]),

@@ -118,6 +118,14 @@ class Automaton:
         data = C.string_at(p.value, n.value) if n.value else b""
         return data, iid.value, nxt.value
 
+    def state_matches(self, ref_state):
+        """Every pattern index ending where the walk enters ref_state, list order."""
+        buf = (C.c_int32 * 4096)()
+        n = self.lib.acm_automaton_state_matches(self.h, ref_state, buf, 4096)
+        if n < 0:
+            raise ValueError("bad state %r" % (ref_state,))
+        return list(buf[:n])
+
     def state_output(self, ref_state):
         return self.lib.acm_automaton_state_output(self.h, ref_state)
 
@@ -201,7 +209,7 @@ class Matcher:
 
     def scan_async(self, d_text, n, init_state=0, stream=None, pat_plane=None, off_plane=None,
                    plane_capacity=None, halo=0, offset_shift=0, workspace=None, wait_before_walk=None,
-                   record_after_walk=None):
+                   record_after_walk=None, report=0):
         """Enqueue one scan of device text; nothing is synchronised.
 
         halo/offset_shift: shard form (acm_scan_shard_async).  workspace: (ptr, nbytes) of a
@@ -209,14 +217,16 @@ class Matcher:
         record_after_walk: hipEvent_t handles chaining the walk kernels of batches that are in
         flight on different streams (acm_scan_batch_async).
         """
-        if wait_before_walk is not None or record_after_walk is not None:
+        if wait_before_walk is not None or record_after_walk is not None or report:
+            if workspace is None and n > self.max_text:
+                raise ValueError("text of %d bytes exceeds reserved %d" % (n, self.max_text))
             st = stream if stream is not None else self.stream
             ws_ptr, ws_bytes = workspace if workspace is not None else (self.ws.ptr, self.ws_bytes)
             b = _lib.ScanBatch(_ptr(d_text), n, halo, offset_shift, init_state, _ptr(ws_ptr), ws_bytes,
                                _ptr(pat_plane) if pat_plane is not None else self.pat_plane.ptr,
                                _ptr(off_plane) if off_plane is not None else self.off_plane.ptr,
                                plane_capacity if plane_capacity is not None else self.plane_capacity,
-                               st, wait_before_walk, record_after_walk)
+                               st, wait_before_walk, record_after_walk, report)
             check(self.lib.acm_scan_batch_async(self.dfa, C.byref(b)), "acm_scan_batch_async")
             return
         if workspace is None and n > self.max_text:
@@ -242,6 +252,33 @@ class Matcher:
             raise AcmError(_lib.ACM_ERR_CAPACITY, "Matcher.fetch",
                            "%d matches but planes hold %d" % (m, stored))
         return off[1:1 + m].astype(np.uint32), pat[1:1 + m].copy(), int(pat[m + 1])
+
+    def scan_all(self, text, init_state=0, out_capacity=None):
+        """All-patterns reporting: scan with the final states in the pattern
+        plane, expand every state's match list on the device (acm_expand_matches_async), download.
+        Returns (offsets, patterns, last_state) with one record per pattern ending at each offset."""
+        t = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) \
+            else np.ascontiguousarray(text, dtype=np.uint8)
+        self.reserve(max(t.size, 1))
+        d = DeviceArray.from_numpy(t, stream=self.stream)
+        cap = out_capacity if out_capacity is not None else 8 * self.plane_capacity
+        max_records = self.plane_capacity - 2
+        ws_bytes = self.lib.acm_expand_workspace_bytes(max_records)
+        ws, pat, off = DeviceArray(ws_bytes), DeviceArray(cap * 4), DeviceArray(cap * 4)
+        try:
+            self.scan_async(d, t.size, init_state, report=_lib.REPORT_STATE)
+            check(self.lib.acm_expand_matches_async(self.dfa, self.pat_plane.ptr, self.off_plane.ptr, max_records,
+                                                    pat.ptr, off.ptr, cap, ws.ptr, ws_bytes, self.stream),
+                  "acm_expand_matches_async")
+            m = int(pat.to_numpy(np.int32, 1, stream=self.stream)[0])
+            if m > cap - 2:
+                raise AcmError(_lib.ACM_ERR_CAPACITY, "Matcher.scan_all", "%d records but planes hold %d" % (m, cap - 2))
+            p = pat.to_numpy(np.int32, m + 2, stream=self.stream)
+            o = off.to_numpy(np.int32, m + 2, stream=self.stream)
+            return o[1:1 + m].astype(np.uint32), p[1:1 + m].copy(), int(p[m + 1])
+        finally:
+            for b in (d, ws, pat, off):
+                b.free()
 
     def scan(self, text, init_state=0):
         """Scan host bytes: upload, scan, download."""

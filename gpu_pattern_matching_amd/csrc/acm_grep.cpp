@@ -70,6 +70,8 @@ double now_us()
 	       "  -t             text mode: one chunk per line\n"
 	       "  -x             patterns are printable hex\n"
 	       "  -M             accepted for compatibility (mapped buffers)\n"
+	       "  -A             report every pattern that ends at an offset, not only the one the\n"
+	       "                 reference reports (extension; off by default)\n"
 	       "  -h             this help\n");
 	exit(EXIT_FAILURE);
 }
@@ -109,7 +111,7 @@ std::vector<std::string> regular_files_in(std::string dir)
 
 struct Config {
 	std::string pat_path, data_path;
-	int dev = -1, hex = 0, verbose = 0, text_mode = 0, follow = 0, threads = 2;
+	int dev = -1, hex = 0, verbose = 0, text_mode = 0, follow = 0, threads = 2, all_patterns = 0;
 	int max_results = MAX_RESULTS, pat_limit = -1;
 	long global_ws = -1, local_ws = -1, chunk = -1;
 };
@@ -132,6 +134,8 @@ struct Buffer {   // one of the two staging buffers of a worker
 	int32_t *h_results = nullptr, *h_results2 = nullptr;
 	void *d_data = nullptr, *d_indices = nullptr, *d_sizes = nullptr, *d_starts = nullptr;
 	void *d_results = nullptr, *d_results2 = nullptr, *d_pat = nullptr, *d_off = nullptr;
+	void *d_pat_all = nullptr, *d_off_all = nullptr, *d_expand_ws = nullptr;   // -A only
+	size_t expand_ws_bytes = 0;
 	void *d_packed = nullptr;
 	size_t chunks = 0, bytes = 0;
 	std::vector<int32_t> starts;
@@ -175,6 +179,12 @@ void buffer_alloc(Buffer &b, const Config &c)
 	CK(acm_rt_malloc(&b.d_results2, plane));
 	CK(acm_rt_malloc(&b.d_pat, (size + 2) * 4));
 	CK(acm_rt_malloc(&b.d_off, (size + 2) * 4));
+	if (c.all_patterns) {
+		b.expand_ws_bytes = acm_expand_workspace_bytes(size);
+		CK(acm_rt_malloc(&b.d_pat_all, (size + 2) * 4));
+		CK(acm_rt_malloc(&b.d_off_all, (size + 2) * 4));
+		CK(acm_rt_malloc(&b.d_expand_ws, b.expand_ws_bytes));
+	}
 }
 
 // binary mode: fixed chunks, a short tail chunk per file (databuf.c:326-407)
@@ -254,12 +264,32 @@ void submit(Worker &w, Buffer &b)
 		    (const int32_t *)b.d_starts, chunks, s));
 		text = b.d_packed;
 	}
-	CK(acm_scan_async(w.sh->dfa, text, stream_len, w.last_state, w.ws, w.ws_bytes, (int32_t *)b.d_pat,
-	    (int32_t *)b.d_off, cap, s));
+	int32_t *pat = (int32_t *)b.d_pat, *off = (int32_t *)b.d_off;
+	if (!c.all_patterns) {
+		CK(acm_scan_async(w.sh->dfa, text, stream_len, w.last_state, w.ws, w.ws_bytes, pat, off, cap, s));
+	} else {   // final states instead of head patterns, then every pattern of each state's match list
+		acm_scan_batch sb;
+		memset(&sb, 0, sizeof(sb));
+		sb.d_text = text;
+		sb.n = stream_len;
+		sb.init_state = w.last_state;
+		sb.d_workspace = w.ws;
+		sb.workspace_bytes = w.ws_bytes;
+		sb.d_pat_plane = pat;
+		sb.d_off_plane = off;
+		sb.plane_capacity = cap;
+		sb.stream = s;
+		sb.report = ACM_REPORT_STATE;
+		CK(acm_scan_batch_async(w.sh->dfa, &sb));
+		CK(acm_expand_matches_async(w.sh->dfa, pat, off, cap - 2, (int32_t *)b.d_pat_all, (int32_t *)b.d_off_all,
+		    cap, b.d_expand_ws, b.expand_ws_bytes, s));
+		pat = (int32_t *)b.d_pat_all;
+		off = (int32_t *)b.d_off_all;
+	}
 	if (!packed)
-		CK(acm_remap_offsets((int32_t *)b.d_off, stream_len, (const int32_t *)b.d_indices,
+		CK(acm_remap_offsets(off, stream_len, (const int32_t *)b.d_indices,
 		    (const int32_t *)b.d_starts, chunks, s));
-	CK(acm_bucketize((const int32_t *)b.d_pat, (const int32_t *)b.d_off, (const int32_t *)b.d_indices,
+	CK(acm_bucketize(pat, off, (const int32_t *)b.d_indices,
 	    (const int32_t *)b.d_sizes, chunks, c.max_results, (int32_t *)b.d_results, (int32_t *)b.d_results2, s));
 	const size_t cells = (size_t)c.max_results * chunks + 1;
 	CK(acm_rt_memcpy_d2h(b.h_results, b.d_results, cells * 4, s));
@@ -379,7 +409,7 @@ int main(int argc, char **argv)
 	Shared sh;
 	Config &c = sh.cfg;
 	int opt;
-	while ((opt = getopt(argc, argv, "f:m:p:tw:vxB:D:FG:L:R:Mh")) != -1) {   // ocl_aho_grep.c:411
+	while ((opt = getopt(argc, argv, "f:m:p:tw:vxB:D:FG:L:R:MhA")) != -1) {   // ocl_aho_grep.c:411 + A
 		switch (opt) {
 		case 'f': c.data_path = optarg; break;
 		case 'm': c.pat_limit = atoi(optarg); break;
@@ -395,6 +425,7 @@ int main(int argc, char **argv)
 		case 'L': c.local_ws = atol(optarg); break;
 		case 'R': c.max_results = atoi(optarg); break;
 		case 'M': break;
+		case 'A': c.all_patterns = 1; break;
 		default: usage();
 		}
 	}

@@ -525,6 +525,18 @@ extern "C" int acm_automaton_pattern(const acm_automaton *a, int index, int *iid
 	return ACM_OK;
 }
 
+extern "C" int acm_automaton_state_matches(const acm_automaton *a, int ref_state, int32_t *out, int cap)
+{
+	if (!a || !a->compiled || ref_state < 0 || (uint32_t)ref_state >= a->num_states || (cap > 0 && !out))
+		return -1;
+	if (!a->is_final_ref((uint32_t)ref_state))
+		return 0;
+	const int32_t len = a->list_len[ref_state];
+	for (int32_t i = 0; i < len && i < cap; i++)
+		out[i] = a->list_pool[(size_t)a->list_begin[ref_state] + i];
+	return len;
+}
+
 extern "C" int acm_automaton_state_output(const acm_automaton *a, int ref_state)
 {
 	if (!a || !a->compiled || ref_state < 0 || (uint32_t)ref_state >= a->num_states)

@@ -25,6 +25,9 @@ struct acm_dfa {
 	uint32_t *d_bloom = nullptr;         // [1 << bloom_log_words] trigrams of the depth-3 states (sparse pipeline)
 	uint32_t bloom_log_words = 15;
 	uint32_t *d_t2g = nullptr;           // [65536] state after bytes (p, c) from the root, index p | c << 8
+	uint32_t *d_list_begin = nullptr;    // [states, reference numbering] offset of the state's match list in d_list_pool
+	uint32_t *d_list_len = nullptr;      // [states] its length (0: not final)
+	int32_t *d_list_pool = nullptr;      // pattern indices, list order
 	size_t device_bytes = 0;
 
 	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies
@@ -44,7 +47,7 @@ struct acm_dfa {
 		size_t workspace_bytes;
 		void *pat_plane, *off_plane;
 		size_t plane_capacity;
-		int mode, chain_bytes, chains_per_lane;
+		int report, mode, chain_bytes, chains_per_lane;
 	};
 	struct GraphEntry {
 		GraphKey key;

@@ -141,6 +141,16 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 			for (uint32_t c = 0; c < 256; c++)
 				t2g[p | (c << 8)] = (uint32_t)rows[(size_t)s1 * 256 + c];
 		}
+		// match lists, for all-patterns reporting (post.hip, acm_expand_matches_async)
+		std::vector<uint32_t> lbegin(n, 0), llen(n, 0);
+		for (uint32_t r = 0; r < n; r++)
+			if (a->is_final_ref(r)) {
+				lbegin[r] = (uint32_t)a->list_begin[r];
+				llen[r] = (uint32_t)a->list_len[r];
+			}
+		if (rc == ACM_OK) rc = upload(&d->d_list_begin, lbegin.data(), lbegin.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_list_len, llen.data(), llen.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload(&d->d_list_pool, a->list_pool.data(), a->list_pool.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_bloom, bloom.data(), bloom.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_t2g, t2g.data(), t2g.size(), &d->device_bytes);
 		d->sparse_ok = !a->patterns.empty();
@@ -182,6 +192,9 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_out);
 		hipFree(d->d_dev2ref);
 		hipFree(d->d_in_byte);
+		hipFree(d->d_list_begin);
+		hipFree(d->d_list_len);
+		hipFree(d->d_list_pool);
 		hipFree(d->d_bloom);
 		hipFree(d->d_t2g);
 		for (auto &g : d->graphs)

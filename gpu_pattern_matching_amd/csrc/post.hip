@@ -11,9 +11,14 @@
 //   bucketize        produces the planes ahomatch.cl writes
 //                    (results[matches*chunks+id], :63-75) from the ordered
 //                    compact planes
+//   expand matches   all-patterns reporting: (offset,
+//                    final state) records -> one record per pattern of the
+//                    state's match list; what walking the next chains of
+//                    acsm_get_patterns_table (acsmx.c:707-721) is meant to give
 #include <hip/hip_runtime.h>
 
 #include "acm_internal.h"
+#include "device_dfa.h"
 
 namespace {
 
@@ -318,6 +323,90 @@ extern "C" int acm_remap_offsets(int32_t *d_off_plane, size_t max_records, const
 		return ACM_OK;
 	hipLaunchKernelGGL(k_remap_offsets, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0,
 	    (hipStream_t)stream, d_off_plane, d_indices, d_packed_start, chunks);
+	ACM_HIP_TRY(hipGetLastError());
+	return ACM_OK;
+}
+
+// ---------------------------------------------------------------- expand ---
+
+namespace {
+
+// records of a compact plane pair: [0] = count, [1 .. count], [count + 1] = final state
+__global__ void k_expand_count(const int32_t *state_plane, uint32_t max_records, const uint32_t *list_len,
+    int32_t *counts)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= max_records)
+		return;
+	const uint32_t m = min((uint32_t)state_plane[0], max_records);
+	counts[i] = i < m ? (int32_t)list_len[state_plane[1 + i]] : 0;
+}
+
+__global__ void k_expand_scatter(const int32_t *state_plane, const int32_t *off_plane, uint32_t max_records,
+    const uint32_t *list_begin, const uint32_t *list_len, const int32_t *list_pool, const int32_t *first_cell,
+    const int32_t *total, int32_t *pat_out, int32_t *off_out, uint32_t out_capacity)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t m_all = (uint32_t)state_plane[0], m = min(m_all, max_records);
+	if (i < m) {
+		const uint32_t st = (uint32_t)state_plane[1 + i], len = list_len[st], from = list_begin[st];
+		const int32_t off = off_plane[1 + i];
+		uint32_t d = (uint32_t)first_cell[i];
+		for (uint32_t j = 0; j < len; j++, d++)
+			if (d + 2 < out_capacity) {
+				pat_out[1 + d] = list_pool[from + j];
+				off_out[1 + d] = off;
+			}
+	}
+	if (i == 0) {   // header and trailer cells, as the scan writes them
+		const uint32_t t = (uint32_t)*total;
+		const int32_t last = state_plane[1 + m];   // trailer of the input (a scan with more records than cells clamps it there)
+		uint32_t tail = t + 1;
+		if (tail > out_capacity - 1)
+			tail = out_capacity - 1;
+		pat_out[0] = (int32_t)t;
+		off_out[0] = (int32_t)t;
+		pat_out[tail] = last;
+		off_out[tail] = last;
+	}
+}
+
+size_t expand_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t acm_expand_workspace_bytes(size_t max_records)
+{
+	return 2 * expand_align((max_records + 1) * sizeof(int32_t)) + 256 +
+	       expand_align(acm_exclusive_scan_workspace_bytes(max_records));
+}
+
+extern "C" int acm_expand_matches_async(const acm_dfa *d, const int32_t *d_state_plane, const int32_t *d_off_plane,
+    size_t max_records, int32_t *d_pat_out, int32_t *d_off_out, size_t out_capacity, void *d_workspace,
+    size_t workspace_bytes, void *stream)
+{
+	if (!d || !d_state_plane || !d_off_plane || !d_pat_out || !d_off_out || out_capacity < 2 ||
+	    max_records == 0 || max_records > 0x7FFFFFFFul)
+		return acm::fail(ACM_ERR_ARG, "acm_expand_matches_async: bad arguments");
+	if (!d_workspace || workspace_bytes < acm_expand_workspace_bytes(max_records))
+		return acm::fail(ACM_ERR_ARG, "acm_expand_matches_async: workspace %zu B < required %zu B",
+		    workspace_bytes, acm_expand_workspace_bytes(max_records));
+	hipStream_t s = (hipStream_t)stream;
+	ACM_HIP_TRY(hipSetDevice(d->device));
+	char *ws = (char *)d_workspace;
+	const size_t plane = expand_align((max_records + 1) * sizeof(int32_t));
+	int32_t *counts = (int32_t *)ws, *cells = (int32_t *)(ws + plane), *total = (int32_t *)(ws + 2 * plane);
+	void *scan_ws = ws + 2 * plane + 256;
+	const uint32_t n = (uint32_t)max_records, blocks = (n + 255) / 256;
+	const uint32_t cap = (uint32_t)(out_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : out_capacity);
+	hipLaunchKernelGGL(k_expand_count, dim3(blocks), dim3(256), 0, s, d_state_plane, n, d->d_list_len, counts);
+	ACM_HIP_TRY(hipGetLastError());
+	const int rc = acm_exclusive_scan_i32(counts, cells, n, total, scan_ws,
+	    acm_exclusive_scan_workspace_bytes(max_records), s);
+	if (rc != ACM_OK)
+		return rc;
+	hipLaunchKernelGGL(k_expand_scatter, dim3(blocks), dim3(256), 0, s, d_state_plane, d_off_plane, n,
+	    d->d_list_begin, d->d_list_len, d->d_list_pool, cells, total, d_pat_out, d_off_out, cap);
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }

@@ -846,6 +846,7 @@ acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b)
 	k.pat_plane = b->d_pat_plane;
 	k.off_plane = b->d_off_plane;
 	k.plane_capacity = b->plane_capacity;
+	k.report = b->report;
 	k.mode = d->scan_mode;
 	k.chain_bytes = d->chain_bytes;
 	k.chains_per_lane = d->chains_per_lane;
@@ -976,6 +977,8 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
 		return acm::fail(ACM_ERR_LIMIT, "acm_scan_async: %zu bytes exceed the 2 GiB buffer limit", n);
 	if (((uintptr_t)d_text & 15) != 0)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: text must be 16-byte aligned");
+	if (batch->report != ACM_REPORT_HEAD && batch->report != ACM_REPORT_STATE)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: report %d is not an ACM_REPORT_* value", batch->report);
 	if (halo > n || offset_shift < INT32_MIN || offset_shift > INT32_MAX ||
 	    (long)n + offset_shift > (long)INT32_MAX)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_shard_async: halo/offset_shift out of range");
@@ -1010,7 +1013,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
 	a.cold = d->d_cold;
 	a.deep = d->d_deep;
 	a.hot = d->d_hot;
-	a.out = d->d_out;
+	// the plane value of a record is a per-state table lookup: the head pattern, or the state's
+	// reference id when the caller wants to expand the whole match list afterwards
+	a.out = batch->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
 	a.dev2ref = d->d_dev2ref;
 	a.in_byte = d->d_in_byte;
 	a.text16 = (const uint4 *)d_text;

@@ -554,7 +554,7 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	memset(&a, 0, sizeof(a));
 	a.cold = d->d_cold;
 	a.deep = d->d_deep;
-	a.out = d->d_out;
+	a.out = b->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
 	a.dev2ref = d->d_dev2ref;
 	a.in_byte = d->d_in_byte;
 	a.bloom = d->d_bloom;

@@ -94,6 +94,11 @@ int acm_automaton_pattern(const acm_automaton *, int index, int *iid, int *n,
     const unsigned char **bytes, int *next_chained);
 /* head-of-match-list pattern index of reference state s, or -1 */
 int acm_automaton_state_output(const acm_automaton *, int ref_state);
+/* every pattern that ends where the walk enters ref_state, in the order of the
+ * state's match list (acsmx.c:299-312, :417-429; the first one is what
+ * acm_automaton_state_output returns).  Writes at most cap indices, returns
+ * the length of the list (0 for a non-final state, -1 on a bad argument). */
+int acm_automaton_state_matches(const acm_automaton *, int ref_state, int32_t *out, int cap);
 
 /* ---------------------------------------------------------------------- */
 /* device-resident DFA                                                     */
@@ -183,7 +188,28 @@ typedef struct acm_scan_batch {
 	void *stream;
 	void *wait_before_walk;		/* hipEvent_t or NULL */
 	void *record_after_walk;	/* hipEvent_t or NULL */
+	int report;			/* ACM_REPORT_* */
 } acm_scan_batch;
+
+/* What the pattern plane of a scan holds per record.
+ *   HEAD   the pattern index the reference reports: the head of the final
+ *          state's match list (acsmx.c:650)
+ *   STATE  the final state itself (reference numbering), for
+ *          acm_expand_matches_async: all-patterns reporting, SURVEY 8(f) row 4 */
+enum { ACM_REPORT_HEAD = 0, ACM_REPORT_STATE = 1 };
+
+/* All-patterns reporting.  Input: the planes of a scan enqueued with
+ * report = ACM_REPORT_STATE (at most max_records records are looked at).
+ * Output, same cell layout ([0] = count, records, trailer = final state): one
+ * record per pattern of each final state's match list -- every pattern that
+ * ends at that offset, in list order, offsets ascending.  The reference never
+ * reports more than the head (ocl_aho_grep.c:276-279 has the table for it,
+ * acsmx.c:707-721); off unless asked for.  Stream-ordered, no host sync. */
+size_t acm_expand_workspace_bytes(size_t max_records);
+int acm_expand_matches_async(const acm_dfa *, const int32_t *d_state_plane,
+    const int32_t *d_off_plane, size_t max_records, int32_t *d_pat_out,
+    int32_t *d_off_out, size_t out_capacity, void *d_workspace,
+    size_t workspace_bytes, void *stream);
 
 int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
 

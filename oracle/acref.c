@@ -521,6 +521,41 @@ orc_scan_serial(const int32_t *table, const unsigned char *text, size_t n,
 	return m;
 }
 
+/*
+ * All-patterns variant: the same walk, but every pattern
+ * of the entered state's match list is reported, in list order -- the list
+ * acsmx.c builds at :299-312 / :417-429 and whose head the table carries
+ * (:650).  The reference has no scanner that does this; its patterns table
+ * links the entries for it (acsmx.c:707-721).
+ */
+size_t
+orc_scan_serial_all(const orc_t *o, const unsigned char *text, size_t n,
+    long init_state, uint32_t *out_pos, int32_t *out_pat, size_t cap,
+    long *final_state)
+{
+	const int32_t *table = o->table;
+	size_t k, m = 0;
+	long state = init_state;
+	int list[4096], len, j;
+	for (k = 0; k < n; k++) {
+		state = table[(size_t)state * 512 + text[k]];
+		if (state < 0) {
+			state = -state;
+			len = orc_match_list(o, (int)state, list, 4096);
+			for (j = 0; j < len && j < 4096; j++) {
+				if (m < cap) {
+					out_pos[m] = (uint32_t)k;
+					out_pat[m] = list[j];
+				}
+				m++;
+			}
+		}
+	}
+	if (final_state)
+		*final_state = state;
+	return m;
+}
+
 /* count-only variant used for timing (no stores besides the counter) */
 size_t
 orc_scan_count(const int32_t *table, const unsigned char *text, size_t n,

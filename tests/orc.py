@@ -190,6 +190,23 @@ class Oracle:
             raise OverflowError("oracle scan: %d matches > cap %d" % (m, cap))
         return pos[:m].copy(), pat[:m].copy(), fs.value
 
+    def scan_all(self, text, init_state=0, cap=None):
+        """Serial scan reporting every pattern of each final state's match list."""
+        t = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray)
+                                 else text, dtype=np.uint8)
+        cap = 8 * t.size + 16 if cap is None else cap
+        pos = np.empty(cap, dtype=np.uint32)
+        pat = np.empty(cap, dtype=np.int32)
+        fs = C.c_long(0)
+        self.L.orc_scan_serial_all.restype = C.c_size_t
+        self.L.orc_scan_serial_all.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.c_long, _u32p, _i32p,
+                                               C.c_size_t, C.POINTER(C.c_long)]
+        m = self.L.orc_scan_serial_all(self.h, _np_ptr(t, _u8p), t.size, init_state, _np_ptr(pos, _u32p),
+                                       _np_ptr(pat, _i32p), cap, C.byref(fs))
+        if m > cap:
+            raise OverflowError("oracle scan_all: %d matches > cap %d" % (m, cap))
+        return pos[:m].copy(), pat[:m].copy(), fs.value
+
     def scan_count(self, text, init_state=0):
         t = np.ascontiguousarray(text, dtype=np.uint8)
         fs = C.c_long(0)

@@ -100,3 +100,29 @@ def test_text_mode(gpu, tmp_path):
 def test_usage_errors(gpu):
     p = subprocess.run([CLI, "-f", "x"], capture_output=True, text=True)
     assert p.returncode != 0 and "No pattern file" in p.stdout
+
+
+def test_all_patterns_flag(gpu, tmp_path):
+    """-A (extension): one line per pattern ending at an offset, in match-list
+    order; without it the output is the reference's (head of the list only)."""
+    words = [b"abc", b"xabc", b"bc", b"c", b"abc"]          # suffixes of each other + a duplicate
+    pat_path = tmp_path / "pats.txt"
+    pat_path.write_bytes(b"\n".join(words) + b"\n")
+    rng = np.random.default_rng(17)
+    text = np.frombuffer(b"abcx ", dtype=np.uint8)[rng.integers(0, 5, size=50000)]
+    text_path = tmp_path / "in.txt"
+    text.tofile(str(text_path))
+    o = orc.Oracle()
+    o.load(str(pat_path))
+    o.compile()
+    base = ["-f", str(text_path), "-p", str(pat_path), "-B", "4096", "-D", "0", "-G", "16", "-L", "1024", "-R", "4096", "-w", "1", "-v"]
+    head_pos, head_pat, _ = o.scan(text)
+    all_pos, all_pat, _ = o.scan_all(text)
+    assert all_pos.size > head_pos.size
+    for flags, pos, pat in (([], head_pos, head_pat), (["-A"], all_pos, all_pat)):
+        hits, stats, _ = run(CLI, base + flags)
+        assert int(stats["Matches"]) == int(stats["Matches reported"]) == pos.size
+        got = [(int(h[3]) - 1, h[1]) for h in hits]
+        want = [(int(p), o.pattern(int(k))[0].decode()) for p, k in zip(pos, pat)]
+        assert got == want
+    o.close()

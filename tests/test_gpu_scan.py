@@ -236,3 +236,58 @@ def test_graph_replay_tracks_buffer_contents(gpu, mode):
         m.set_graphs(False)
         m.set_mode("auto")
         d.free()
+
+
+@pytest.mark.parametrize("name", ["tests", "sentiment", "clamav2000"])
+def test_all_patterns_reporting(gpu, name):
+    """scan with the final states in the pattern plane, expand every state's
+    match list on the device -> one record per pattern ending at each offset, in list order.
+    The default planes (head only) stay what the reference reports."""
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    if name == "sentiment":
+        text = fixtures.text_for({"kind": "words", "n": 200003, "seed": 8}, None)
+    else:
+        text = fixtures.text_for({"kind": "clamav", "n": 200003, "seed": 8, "n_plant": 300}, pats)
+    m = matcher_for(name)
+    modes = ["chain", "sparse"] if m.sparse_eligible() else ["chain"]
+    exp_all, exp_head = o.scan_all(text), o.scan(text)
+    assert exp_all[0].size >= exp_head[0].size
+    if name == "sentiment":
+        assert exp_all[0].size > exp_head[0].size      # nested words: more than one pattern per offset
+    try:
+        for mode in modes:
+            m.set_mode(mode)
+            assert_same(m.scan_all(text), exp_all)
+            assert_same(m.scan(text), exp_head)
+            for init in (0, exp_head[2]):
+                assert_same(m.scan_all(text[:5000], init), o.scan_all(text[:5000], init))
+    finally:
+        m.set_mode("auto")
+
+
+def test_all_patterns_nested_set_sparse(gpu):
+    """Match lists longer than one entry through the sparse pipeline (patterns of >= 3 bytes that
+    are suffixes of each other, and a duplicate)."""
+    pats = [b"abcabc", b"bcabc", b"cabc", b"abc", b"abc", b"bca", b"xabcabc"]
+    a = Automaton()
+    o = orc.Oracle()
+    for i, p in enumerate(pats):
+        a.add(p, 10 + i)
+        o.add(p, 10 + i)
+    a.compile()
+    o.compile()
+    m = Matcher(a, 0, max_text=1 << 16)
+    assert m.sparse_eligible()
+    rng = np.random.default_rng(3)
+    text = np.frombuffer(b"abcx", dtype=np.uint8)[rng.integers(0, 4, size=60000)]
+    exp = o.scan_all(text)
+    assert exp[0].size > o.scan(text)[0].size
+    for mode in ("chain", "sparse"):
+        m.set_mode(mode)
+        assert_same(m.scan_all(text, out_capacity=exp[0].size + 2), exp)
+    with pytest.raises(AcmError) as e:
+        m.scan_all(text, out_capacity=100)             # too small for the expansion: reported
+    assert e.value.code == -8
+    m.close()
+    a.close()

@@ -163,3 +163,25 @@ def test_empty_pattern_never_reports(lib):
     # become final (acsmx.c:417-429), depth-1 states do not (:376-382): "ab" reports index 0
     pos, pat, _ = o.scan(b"xxabxx")
     assert pos.tolist() == [3] and pat.tolist() == [0]
+
+
+@pytest.mark.parametrize("name", ["tests", "tests1", "sentiment", "clamav2000_m12"])
+def test_state_match_lists_equal_oracle(lib, name):
+    """acm_automaton_state_matches (all-patterns reporting) = the oracle's match lists, which
+    test_oracle_equals_compiled_reference pins against acsmx.c; the head is what the table reports."""
+    o = fixtures.oracle_for(name)
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    assert a.num_states == o.num_states
+    multi = 0
+    for s in range(0, o.num_states, max(1, o.num_states // 5000)):
+        exp = o.match_list(s) if s else []          # the root is never reported (transitions into 0 are not final)
+        got = a.state_matches(s)
+        assert got == exp, s
+        assert a.state_output(s) == (exp[0] if exp else -1)
+        multi += len(exp) > 1
+    if name == "sentiment":
+        assert multi > 0                            # nested patterns: lists longer than the head
+    a.close()

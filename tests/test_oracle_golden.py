@@ -124,6 +124,21 @@ def test_oracle_equals_compiled_reference(name):
     a = r.scan(text, init)
     b = o.scan(text, init)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    # all-patterns walk: every pattern of the reference's own match list of
+    # the state entered at each hit, walked over the reference's own table
+    table = r.table().reshape(-1, 512)
+    small = text[:1 << 14]
+    exp_pos, exp_pat, state = [], [], init
+    for k, c in enumerate(small):
+        nxt = int(table[state, c])
+        if nxt < 0:
+            nxt = -nxt
+            for p in r.match_list(nxt):
+                exp_pos.append(k)
+                exp_pat.append(p)
+        state = nxt
+    got = o.scan_all(small, init)
+    assert got[0].tolist() == exp_pos and got[1].tolist() == exp_pat and got[2] == state
 
 
 def test_reference_hex_decoder_agrees():
