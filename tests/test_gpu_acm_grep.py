@@ -126,3 +126,46 @@ def test_all_patterns_flag(gpu, tmp_path):
         want = [(int(p), o.pattern(int(k))[0].decode()) for p, k in zip(pos, pat)]
         assert got == want
     o.close()
+
+
+def test_follow_mode_sees_appended_data(gpu, tmp_path):
+    """-F (ocl_aho_grep.c:96-99): the worker keeps polling its files; data appended later is scanned
+    from the state the earlier data left (a signature cut by the append boundary is found), and
+    SIGINT ends the run with the STATS block."""
+    import signal
+    import time
+    name = "clamav2000_m12"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    path, hx, ml = fixtures.set_source(name)
+    whole = fixtures.text_for({"kind": "clamav", "n": 180000, "seed": 91, "n_plant": 90}, pats).copy()
+    cut = 100000
+    sig = np.frombuffer(pats[7], dtype=np.uint8)
+    whole[cut - 5:cut - 5 + sig.size] = sig              # straddles the append boundary
+    f = tmp_path / "growing.bin"
+    whole[:cut].tofile(str(f))
+    args = [CLI, "-f", str(f), "-p", path, "-x", "-m", "12", "-B", "4096", "-D", "0", "-G", "64", "-L", "1024",
+            "-w", "1", "-v", "-F"]
+    p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        time.sleep(6)
+        with open(str(f), "ab") as fh:
+            fh.write(whole[cut:].tobytes())
+        time.sleep(6)
+        p.send_signal(signal.SIGINT)
+        out, err = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    out = out.decode(errors="replace")
+    assert p.returncode == 0, out[-1500:] + err.decode(errors="replace")[-1500:]
+    pos, pat, _ = o.scan(whole)
+    stats = dict(re.findall(r"^([A-Za-z ()]+):\s+([\d.]+)$", out, flags=re.M))
+    assert int(stats["Matches"]) == pos.size
+    assert int(stats["Processed bytes"]) == whole.size
+    assert int(stats["Kernel launches"]) >= 2            # the appended part came in a later round
+    assert int(stats["Matches reported"]) == pos.size
+    # the -v lines whose (binary) pattern text survives line splitting come in scan order
+    iids = [int(m.group(1)) for m in (LINE.match(l) for l in out.splitlines()) if m]
+    want = iter(o.pattern(int(k))[1] for k in pat)
+    assert len(iids) > pos.size // 2 and all(any(i == w for w in want) for i in iids)
