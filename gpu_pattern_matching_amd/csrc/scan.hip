@@ -111,6 +111,7 @@ struct ScanArgs {
 	int32_t *off_plane;
 	uint32_t plane_capacity;
 	const uint32_t *only_if;   // when set: run only if this device word is non-zero
+	uint32_t fold_blocks;      // > 0: off[] holds the raw totals of this many blocks; the scatter adds them up itself
 };
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 // up-sweep / down-sweep in LDS.  Also publishes the grand total.
 constexpr int kTopThreads = 1024;
 constexpr uint32_t kTopMax = kTopThreads * 64;
+constexpr uint32_t kFoldMax = 8192;   // block totals a scatter block still adds up by itself (64 MiB at S = 32)
 
 __global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t nb)
 {
@@ -611,7 +613,38 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 	if (lane == 63)
 		wtot[wv] = inc;
 	__syncthreads();
-	uint32_t before = (uint32_t)a.off[blockIdx.x];
+	uint32_t before, total_records = 0;
+	if (a.fold_blocks) {
+		// no separate scan launch over the block totals: every block adds up the ones in front of
+		// it (a few thousand L2-resident words), block 0 also all of them for the header cell
+		__shared__ uint32_t part[kBlock2 / 64], part_all[kBlock2 / 64];
+		uint32_t mine = 0, all = 0;
+		const uint32_t upto = blockIdx.x == 0 ? a.fold_blocks : blockIdx.x;
+		for (uint32_t i = tid; i < upto; i += kBlock2) {
+			const uint32_t v = (uint32_t)a.off[i];
+			all += v;
+			mine += i < blockIdx.x ? v : 0u;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			mine += __shfl_xor(mine, o, 64);
+			all += __shfl_xor(all, o, 64);
+		}
+		if (lane == 0) {
+			part[wv] = mine;
+			part_all[wv] = all;
+		}
+		__syncthreads();
+		before = 0;
+		for (uint32_t w = 0; w < kBlock2 / 64; w++) {
+			before += part[w];
+			total_records += part_all[w];
+		}
+	} else {
+		before = (uint32_t)a.off[blockIdx.x];
+		if (blockIdx.x == 0 && tid == 0)
+			total_records = a.misc[1];
+	}
 	for (uint32_t w = 0; w < wv; w++)
 		before += wtot[w];
 	off[tid] = before + inc - c;
@@ -645,7 +678,7 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 			drain(a.stage1 + (((size_t)wt * C * 64) << a.logS), a.wave_cnt1[wt], true);
 	}
 	if (blockIdx.x == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
-		const uint32_t total = a.misc[1];
+		const uint32_t total = total_records;
 		const int32_t last_ref = (int32_t)a.dev2ref[a.misc[0]];
 		uint32_t tail = total + 1;
 		if (tail > a.plane_capacity - 1)
@@ -753,7 +786,7 @@ extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 	return d->chains_per_lane;
 }
 
-extern "C" int acm_scan_kernel_count(void) { return 5; }
+extern "C" int acm_scan_kernel_count(void) { return 4; }
 
 namespace {
 // tiny texts are not worth the extra launches
@@ -1097,7 +1130,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
 	hipLaunchKernelGGL(k_probe, dim3(nb), dim3(kBlock2), 0, s, a);
 	hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
-	if (nb <= kTopMax) {
+	if (nb <= kFoldMax) {
+		a.fold_blocks = nb;   // the scatter kernel sums the block totals itself: one launch less
+	} else if (nb <= kTopMax) {
 		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kTopThreads), 0, s, a, nb);
 	} else {  // > 16M chains: generic multi-level scan of the block totals
 		rc = acm_exclusive_scan_i32(a.off, a.off, nb, (int32_t *)(a.misc + 1), ws + l.scan_ws,

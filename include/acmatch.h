@@ -217,7 +217,8 @@ int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
  * Returns the value in use. */
 int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
 
-/* number of kernels one acm_scan_async enqueues for a non-empty text (chain pipeline) */
+/* number of kernels the chain pipeline enqueues for a non-empty text of up to
+ * 64 MiB (one more above that) */
 int acm_scan_kernel_count(void);
 
 /* A scan whose arguments repeat (same text buffer, size, workspace, planes,

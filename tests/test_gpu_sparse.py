@@ -214,4 +214,7 @@ def test_beyond_the_fused_block_limit(gpu):
     exp = o.scan(text)
     assert_same(m.scan(text), exp)
     assert m.path_taken(n) == "sparse"
+    m.set_mode("chain")          # and the chain pipeline's separate scan launch over > 8192 block totals
+    m.set_chain_bytes(32)
+    assert_same(m.scan(text), exp)
     m.close()
