@@ -315,7 +315,7 @@ def main():
         # cannot be collected inside a timed run, so this is read back, never estimated
         traffic = None
         stage_traffic = {}
-        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r1_traffic_chain.json" if path == "chain" else "r1_traffic.json")
         if os.path.exists(tfile) and args.sigs == 2000 and args.max_len < 0:
             for name, rec in json.load(open(tfile)).items():
                 for k in kernels:

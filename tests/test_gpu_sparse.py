@@ -218,3 +218,37 @@ def test_beyond_the_fused_block_limit(gpu):
     m.set_chain_bytes(32)
     assert_same(m.scan(text), exp)
     m.close()
+
+
+def test_capacity_overflow_in_sparse_mode(gpu):
+    """Planes smaller than the result: the count is still exact, the first capacity-2 records and
+    the state in the last cell are there, fetch reports ACM_ERR_CAPACITY (same contract as the
+    chain pipeline, compactarray.cl:49-55 cell layout)."""
+    from gpu_pattern_matching_amd import AcmError
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    text = fixtures.text_for({"kind": "clamav", "n": 1 << 20, "seed": 5, "n_plant": 1000}, pats)
+    exp = o.scan(text)
+    assert exp[0].size > 200
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=text.size, plane_capacity=100)
+    a.close()
+    m.set_mode("sparse")
+    d = DeviceArray.from_numpy(text)
+    m.scan_async(d, text.size)
+    with pytest.raises(AcmError) as e:
+        m.fetch()
+    assert e.value.code == -8
+    assert m.path_taken(text.size) == "sparse"
+    pat = m.pat_plane.to_numpy(np.int32, 100)
+    off = m.off_plane.to_numpy(np.int32, 100)
+    assert pat[0] == exp[0].size
+    assert np.array_equal(off[1:99], exp[0][:98].astype(np.int32))
+    assert np.array_equal(pat[1:99], exp[1][:98])
+    assert pat[99] == exp[2]
+    d.free()
+    m.close()
