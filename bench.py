@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the reference's headline workload on MI355X.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -44,8 +44,8 @@ def log(rank, *a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sigs", type=int, default=2000, choices=[2000, 10000, 15000])
     ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
     ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
