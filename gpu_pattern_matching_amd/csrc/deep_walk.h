@@ -56,23 +56,17 @@ __device__ __forceinline__ Deep deep_step(const A &a, uint32_t state, uint32_t b
 }
 
 // XOR of the 16 bytes at two arbitrarily aligned addresses, as two 64-bit
-// words: each side comes from the five aligned dwords that cover it (plain
-// registers all the way -- a by-value 16-byte object here ends up as a private
-// array the compiler parks in LDS).  Reads up to p + 20 / q + 20.
-__device__ __forceinline__ uint32_t dword_at(const uint32_t *q, uint32_t i, uint32_t sh)
-{
-	return __builtin_amdgcn_alignbyte(q[i + 1], q[i], sh);
-}
+// words.  gfx950 under HSA runs with unaligned access enabled: a packed
+// 16-byte load is ONE global_load_dwordx4 whatever the address.
+struct __attribute__((packed)) Unaligned16 {
+	uint64_t lo, hi;
+};
 
 __device__ __forceinline__ void diff_bytes16(const uint8_t *p, const uint8_t *q, uint64_t &lo, uint64_t &hi)
 {
-	const uint32_t *pa = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
-	const uint32_t *qa = (const uint32_t *)((uintptr_t)q & ~(uintptr_t)3);
-	const uint32_t ps = (uint32_t)((uintptr_t)p & 3), qs = (uint32_t)((uintptr_t)q & 3);
-	const uint32_t x0 = dword_at(pa, 0, ps) ^ dword_at(qa, 0, qs), x1 = dword_at(pa, 1, ps) ^ dword_at(qa, 1, qs);
-	const uint32_t x2 = dword_at(pa, 2, ps) ^ dword_at(qa, 2, qs), x3 = dword_at(pa, 3, ps) ^ dword_at(qa, 3, qs);
-	lo = (uint64_t)x0 | ((uint64_t)x1 << 32);
-	hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+	const Unaligned16 *x = (const Unaligned16 *)p, *y = (const Unaligned16 *)q;
+	lo = x->lo ^ y->lo;
+	hi = x->hi ^ y->hi;
 }
 
 // bytes two 16-byte windows agree on before the first difference (16: all)
@@ -92,13 +86,13 @@ __device__ __forceinline__ uint32_t agree16(const uint8_t *p, const uint8_t *q)
 // level moves the walk up to 16 bytes.  (64 bytes per level -- four compares
 // in flight, always or only after a first full 16 -- was measured slower on
 // every percentile of the walk times, not just for short runs.)  Returns the
-// bytes consumed.  Stops 20 bytes short of the padded end of the text: the
+// bytes consumed.  Stops at the last full 16 bytes of the padded text: the
 // caller single-steps there.
 template <class A>
 __device__ __forceinline__ uint32_t fast_forward(const A &a, Deep &d, uint32_t pos, uint32_t limit)
 {
 	uint32_t total = 0;
-	while (d.run != 0 && total < limit && pos + total + 20 <= a.n_pad) {
+	while (d.run != 0 && total < limit && pos + total + 16 <= a.n_pad) {
 		const uint32_t want = min(min(d.run, limit - total), 16u);
 		const uint32_t same = min(agree16(a.in_byte + d.s + 1, a.text + pos + total), want);
 		d.s += same;
