@@ -14,7 +14,8 @@ flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144
 steps are issued round-robin on --workers HIP streams with private scratch, so the
 latency-bound tail of one batch overlaps the walk of the next.  With N > 1 GPUs the logical
 text is N x 32 MiB, rank g scans shard g (+ an (L-1)-byte halo), the DFA is replicated and
-every step ends with the RCCL gather of the compact match planes to rank 0 (double-buffered).
+the compact match planes of every round of --workers steps go to rank 0 in one RCCL gather
+(double-buffered: it overlaps the next round's scans).
 Weak scaling: 32 MiB per GPU.
 
 Prints ONE JSON line on rank 0.
@@ -136,19 +137,27 @@ def main():
     d_text = torch.zeros((n_local + 15) // 16 * 16, dtype=torch.uint8, device=dev)
     d_text[:n_local] = torch.from_numpy(mine).to(dev)
     ws_bytes = matcher.lib.acm_scan_workspace_bytes(matcher.dfa, n_local)
-    cap = 1 << 16                                   # cells per plane; 3.8k records expected
+    cap = 1 << 14                                   # cells per plane; 3.8k records expected
+    while cap < 2 * args.plant + 1024:
+        cap *= 2
     W = max(1, args.workers)
 
     class Worker:
         def __init__(self):
             self.stream = torch.cuda.Stream(device=dev)
             self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            self.planes = [torch.zeros((2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-            self.pending = [None, None]
-            self.gathered = [[torch.empty((2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
-                             for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+            self.scanned = torch.cuda.Event()       # recorded behind the worker's latest scan
 
     workers = [Worker() for _ in range(W)]
+    # Match planes of one round (W consecutive steps, one per worker) sit in one tensor and travel
+    # to rank 0 in ONE gather: a collective per step would cost more host time than the scan it
+    # follows.  Two such tensors, so the gather of round r overlaps the scans of round r + 1.
+    planes = [torch.zeros((W, 2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [[torch.empty((W, 2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
+                for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    gather_stream = torch.cuda.Stream(device=dev)
+    gather_done = [None, None]                      # event behind the last gather of each tensor
+    open_round = {"buf": None, "workers": []}       # scans issued but not gathered yet
     # the walk kernels of consecutive batches are chained by events (batch k+1's walk starts when
     # batch k's walk is done): only the walks serialise, everything behind them overlaps
     walk_done = []
@@ -159,14 +168,38 @@ def main():
     issued = [0]
     torch.cuda.synchronize()
 
+    def flush():
+        """Gather the planes of the round that is open (all of its scans are enqueued)."""
+        buf, ws_ = open_round["buf"], open_round["workers"]
+        open_round["buf"], open_round["workers"] = None, []
+        if buf is None or world == 1:
+            return
+        if backend == "nccl":
+            for wk in ws_:
+                gather_stream.wait_event(wk.scanned)
+            with torch.cuda.stream(gather_stream):
+                dist.gather(planes[buf], gather_list=gathered[buf] if rank == 0 else None, dst=0)
+                done = torch.cuda.Event()
+                done.record(gather_stream)
+            gather_done[buf] = done
+        else:   # rehearsal: through the host
+            for wk in ws_:
+                wk.stream.synchronize()
+            host = planes[buf].cpu()
+            bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, gather_list=bufs, dst=0)
+            if rank == 0:
+                for g, h in zip(gathered[buf], bufs):
+                    g.copy_(h)
+
     def step(k):
-        wk = workers[k % W]
-        buf = (k // W) & 1
-        if wk.pending[buf] is not None:             # the gather that last used this buffer:
-            with torch.cuda.stream(wk.stream):      # the worker's stream waits for it, not the host
-                wk.pending[buf].wait()
-            wk.pending[buf] = None
-        p = wk.planes[buf]
+        w, buf = k % W, (k // W) & 1
+        wk = workers[w]
+        if open_round["buf"] is not None and (open_round["buf"] != buf or wk in open_round["workers"]):
+            flush()                                 # a new round begins
+        if gather_done[buf] is not None:            # the gather that last read this tensor:
+            wk.stream.wait_event(gather_done[buf])  # the worker's stream waits for it, not the host
+        p = planes[buf][w]
         i = issued[0]
         issued[0] += 1
         chain = args.chain_walks and W > 1
@@ -175,26 +208,16 @@ def main():
                            offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes),
                            wait_before_walk=wait,
                            record_after_walk=walk_done[i % len(walk_done)] if chain else None)
-        if world > 1 and backend == "nccl":
-            with torch.cuda.stream(wk.stream):
-                wk.pending[buf] = dist.gather(p, gather_list=wk.gathered[buf] if rank == 0 else None,
-                                              dst=0, async_op=True)
-        elif world > 1:   # rehearsal: through the host
-            wk.stream.synchronize()
-            host = p.cpu()
-            bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, gather_list=bufs, dst=0)
-            if rank == 0:
-                for g, h in zip(wk.gathered[buf], bufs):
-                    g.copy_(h)
+        if world > 1:
+            wk.scanned.record(wk.stream)
+        open_round["buf"] = buf
+        open_round["workers"].append(wk)
+        if len(open_round["workers"]) == W:
+            flush()
 
     def drain():
-        for wk in workers:
-            for b in (0, 1):
-                if wk.pending[b] is not None:
-                    with torch.cuda.stream(wk.stream):
-                        wk.pending[b].wait()
-                    wk.pending[b] = None
+        flush()
+        gather_stream.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -242,8 +265,8 @@ def main():
 
     # ---- results of the last step -------------------------------------------------------------
     k_last = max(args.steps - 1, 0)
-    wk_last, last = workers[k_last % W], (k_last // W) & 1
-    local = wk_last.planes[last].cpu().numpy()
+    w_last, last = k_last % W, (k_last // W) & 1
+    local = planes[last][w_last].cpu().numpy()
     m_local = int(local[0, 0])
     m_total = m_local
     if world > 1:
@@ -254,7 +277,7 @@ def main():
     out = None
     if rank == 0:
         if world > 1:
-            offs, pids, last_state = sharding.merge_gathered(wk_last.gathered[last])
+            offs, pids, last_state = sharding.merge_gathered([g[w_last] for g in gathered[last]])
         else:
             offs, pids, last_state = sharding.merge_gathered([local])
         assert offs.size == m_total
