@@ -252,3 +252,43 @@ def test_capacity_overflow_in_sparse_mode(gpu):
     assert pat[99] == exp[2]
     d.free()
     m.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_pattern_sets(gpu, seed):
+    """Random sets (3..40 bytes, small alphabets so that prefixes, suffixes and whole patterns
+    collide a lot; duplicates allowed) x random and pattern-laced texts, carried-in states: sparse
+    = chain = oracle, head-only and all-patterns."""
+    rng = np.random.default_rng(1000 + seed)
+    sigma = int(rng.integers(2, 6))
+    npat = int(rng.integers(1, 40))
+    pats = []
+    for _ in range(npat):
+        ln = int(rng.integers(3, 41 if rng.random() < 0.3 else 9))
+        if pats and rng.random() < 0.4:        # extend or cut an earlier one
+            base = pats[int(rng.integers(len(pats)))]
+            cut = int(rng.integers(1, len(base) + 1))
+            body = (base[:cut] if rng.random() < 0.5 else base[-cut:]) + bytes(rng.integers(97, 97 + sigma, size=ln, dtype=np.uint8))
+            body = body[:max(3, ln)] if len(body) >= 3 else body + b"aaa"
+            pats.append(bytes(body))
+        else:
+            pats.append(bytes(rng.integers(97, 97 + sigma, size=ln, dtype=np.uint8)))
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 17, plane_capacity=1 << 18)
+    assert m.sparse_eligible()
+    for n in (64, 1000, 70001, 1 << 17):
+        text = rng.integers(97, 97 + sigma + 1, size=n, dtype=np.uint8)   # one letter outside the alphabet
+        for _ in range(n // 200):
+            p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+            at = int(rng.integers(0, max(1, n - p.size)))
+            text[at:at + p.size] = p[:n - at]
+        init = int(rng.integers(0, o.num_states)) if n < 70001 else 0
+        exp, exp_all = o.scan(text, init), o.scan_all(text, init)
+        for mode in ("sparse", "chain"):
+            m.set_mode(mode)
+            assert_same(m.scan(text, init), exp)
+            if n <= 1000:
+                assert_same(m.scan_all(text, init, out_capacity=exp_all[0].size + 2), exp_all)
+    m.close()
+    a.close()
+    o.close()
