@@ -292,3 +292,36 @@ def test_random_pattern_sets(gpu, seed):
     m.close()
     a.close()
     o.close()
+
+
+def test_gibibyte_buffer(gpu):
+    """A single 1 GiB + 12345 byte buffer (the API takes up to 2 GiB - 17): offsets above 2^30,
+    65 000+ blocks, signatures planted across every kind of internal boundary -- both pipelines
+    against the oracle's serial scan."""
+    name = "clamav2000"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    n = (1 << 30) + 12345
+    piece = fixtures.text_for({"kind": "clamav", "n": 1 << 26, "seed": 21, "n_plant": 5000}, pats)
+    text = np.empty(n, dtype=np.uint8)
+    for at in range(0, n, piece.size):          # 16 shifted copies of a 64 MiB piece + the tail
+        m_ = min(piece.size, n - at)
+        text[at:at + m_] = np.roll(piece, at >> 20)[:m_]
+    sig = np.frombuffer(pats[11], dtype=np.uint8)
+    for at in (n - sig.size, (1 << 30) - 7, (1 << 29) + (1 << 15) - 3, (1 << 28) - 1):
+        text[at:at + sig.size] = sig
+    exp = o.scan(text, cap=1 << 21)
+    assert exp[0].size > 70000 and int(exp[0][-1]) == n - 1
+    path, hx, ml = fixtures.set_source(name)
+    a = Automaton()
+    a.load_file(path, hx, ml)
+    a.compile()
+    m = Matcher(a, 0, max_text=n, plane_capacity=1 << 21)
+    a.close()
+    for mode in ("sparse", "chain"):
+        m.set_mode(mode)
+        assert_same(m.scan(text), exp)
+    m.set_mode("sparse")
+    m.scan(text)
+    assert m.path_taken(n) == "sparse"
+    m.close()
