@@ -208,6 +208,11 @@ def test_bad_arguments(gpu, lib):
         m.scan_async(d, 16, init_state=10 ** 6)        # not a state
     with pytest.raises(AcmError):
         m.scan_async(d.ptr + 1, 16)                    # misaligned text
+    with pytest.raises(AcmError) as e:
+        m.scan_async(d, 1 << 31, workspace=(m.ws, m.ws_bytes))   # beyond the 2 GiB - 17 buffer limit
+    assert e.value.code == -5
+    with pytest.raises(AcmError):
+        m.scan_async(d, 16, report=7)                  # not an ACM_REPORT_* value
     d.free()
 
 
