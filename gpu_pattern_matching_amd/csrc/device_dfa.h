@@ -1,6 +1,7 @@
 // acm_dfa: the device-resident automaton (layout described in device_dfa.hip).
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <vector>
@@ -29,6 +30,11 @@ struct acm_dfa {
 	uint32_t *d_list_len = nullptr;      // [states] its length (0: not final)
 	int32_t *d_list_pool = nullptr;      // pattern indices, list order
 	size_t device_bytes = 0;
+
+	// adaptive AUTO mode (scan.hip, pick_sparse): batches the sparse kernels gave up on, counted by
+	// the device in pinned host memory
+	uint32_t *h_giveups = nullptr, *d_giveups = nullptr;
+	mutable std::atomic<uint32_t> sparse_batches{0}, giveups_seen{0}, chain_hold{0};
 
 	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies
 	int scan_mode = ACM_SCAN_MODE_AUTO;

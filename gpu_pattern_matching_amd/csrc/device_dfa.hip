@@ -168,6 +168,16 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		acm_dfa_release(d);
 		return ACM_ERR_HIP;
 	}
+	if (d->sparse_ok && hipHostMalloc((void **)&d->h_giveups, 64, hipHostMallocMapped) == hipSuccess) {
+		*d->h_giveups = 0;
+		if (hipHostGetDevicePointer((void **)&d->d_giveups, d->h_giveups, 0) != hipSuccess)
+			d->d_giveups = nullptr;
+	}
+	if (!d->d_giveups && d->h_giveups) {   // no adaptive mode without the counter
+		hipHostFree(d->h_giveups);
+		d->h_giveups = nullptr;
+	}
+	(void)hipGetLastError();
 	if (const char *m = getenv("ACM_SCAN_MODE")) {   // debugging aid: same as acm_scan_set_mode
 		if (!strcmp(m, "chain")) d->scan_mode = ACM_SCAN_MODE_CHAIN;
 		else if (!strcmp(m, "sparse")) d->scan_mode = ACM_SCAN_MODE_SPARSE;
@@ -197,6 +207,8 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_list_pool);
 		hipFree(d->d_bloom);
 		hipFree(d->d_t2g);
+		if (d->h_giveups)
+			hipHostFree(d->h_giveups);
 		for (auto &g : d->graphs)
 			if (g.exec)
 				hipGraphExecDestroy((hipGraphExec_t)g.exec);

@@ -48,6 +48,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdint>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -103,7 +104,7 @@ struct ScanArgs {
 	int32_t *off;           // [blocks] per-256-chain totals, scanned in place
 	uint32_t *wave_cnt1;
 	uint32_t *wave_cnt2;
-	uint32_t *misc;         // [0] last state (dev), [1] total records
+	uint32_t *misc;         // [0] last state (dev), [1] total records, [2] which pipeline produced the planes
 	uint2 *stage1;
 	uint2 *stage2;
 	// output
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 	if (blockIdx.x == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
 		const uint32_t total = total_records;
 		const int32_t last_ref = (int32_t)a.dev2ref[a.misc[0]];
+		a.misc[2] = a.only_if ? 3u : (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
 		uint32_t tail = total + 1;
 		if (tail > a.plane_capacity - 1)
 			tail = a.plane_capacity - 1;
@@ -696,6 +698,7 @@ __global__ void k_finalize_empty(ScanArgs a)
 	if (threadIdx.x != 0 || blockIdx.x != 0)
 		return;
 	const int32_t last_ref = (int32_t)a.dev2ref[a.init_state];
+	a.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;
 	a.pat_plane[0] = 0;
 	a.off_plane[0] = 0;
 	a.pat_plane[1] = last_ref;
@@ -789,10 +792,28 @@ extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 extern "C" int acm_scan_kernel_count(void) { return 4; }
 
 namespace {
-// tiny texts are not worth the extra launches
-bool use_sparse(const acm_dfa *d, size_t n)
+// Which pipeline the next batch gets.  Tiny texts are not worth the extra launches.  In AUTO
+// mode the choice adapts: a batch the sparse kernels give up on costs both pipelines, so when
+// half of the last 16 sparse batches ended that way (dense matches, endless deep runs) the next
+// 64 go to the chain pipeline directly, then the sparse one is tried again.
+bool pick_sparse(const acm_dfa *d, size_t n)
 {
-	return d->sparse_ok && d->scan_mode != ACM_SCAN_MODE_CHAIN && n >= 64;
+	if (!d->sparse_ok || d->scan_mode == ACM_SCAN_MODE_CHAIN || n < 64)
+		return false;
+	if (d->scan_mode != ACM_SCAN_MODE_AUTO || !d->h_giveups)
+		return true;
+	uint32_t hold = d->chain_hold.load(std::memory_order_relaxed);
+	while (hold > 0)
+		if (d->chain_hold.compare_exchange_weak(hold, hold - 1, std::memory_order_relaxed))
+			return false;
+	const uint32_t count = d->sparse_batches.fetch_add(1, std::memory_order_relaxed) + 1;
+	if (count % 16 == 0) {
+		const uint32_t seen = *(volatile uint32_t *)d->h_giveups;   // written by k_sparse_emit, may lag
+		const uint32_t before = d->giveups_seen.exchange(seen, std::memory_order_relaxed);
+		if (seen - before >= 8)
+			d->chain_hold.store(64, std::memory_order_relaxed);
+	}
+	return true;
 }
 }  // namespace
 
@@ -813,13 +834,12 @@ extern "C" int acm_scan_path_taken(const acm_dfa *d, const void *d_workspace, si
 		return acm::fail(ACM_ERR_ARG, "acm_scan_path_taken: bad arguments");
 	ACM_HIP_TRY(hipSetDevice(d->device));
 	ACM_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-	if (!use_sparse(d, n))
+	if (n == 0)
 		return ACM_SCAN_MODE_CHAIN;
 	const Layout l = layout_for(n);
-	uint32_t gave_up = 0;
-	ACM_HIP_TRY(hipMemcpy(&gave_up, (const char *)d_workspace + l.sparse +
-	    acm::sparse_workspace_bytes(n) - 256, 4, hipMemcpyDeviceToHost));
-	return gave_up ? 3 : ACM_SCAN_MODE_SPARSE;
+	uint32_t marker = 0;   // misc[2]: written by whichever pipeline produced the planes
+	ACM_HIP_TRY(hipMemcpy(&marker, (const char *)d_workspace + l.misc + 8, 4, hipMemcpyDeviceToHost));
+	return (int)marker;
 }
 
 extern "C" int acm_scan_async(const acm_dfa *d, const void *d_text, size_t n, long init_state,
@@ -862,10 +882,10 @@ int scan_prepare(const acm_dfa *)
 }  // namespace acm
 
 namespace {
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch);
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse);
 
 // what a cached graph was captured for: every input of enqueue_batch except the stream
-acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b)
+acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b, bool sparse)
 {
 	acm_dfa::GraphKey k;
 	memset(&k, 0, sizeof(k));
@@ -880,7 +900,7 @@ acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b)
 	k.off_plane = b->d_off_plane;
 	k.plane_capacity = b->plane_capacity;
 	k.report = b->report;
-	k.mode = d->scan_mode;
+	k.mode = sparse ? ACM_SCAN_MODE_SPARSE : ACM_SCAN_MODE_CHAIN;
 	k.chain_bytes = d->chain_bytes;
 	k.chains_per_lane = d->chains_per_lane;
 	return k;
@@ -896,11 +916,12 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 {
 	if (!batch)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: null batch");
+	const bool sparse = d && pick_sparse(d, batch->n);
 	if (!d || !d->use_graphs || d->profile || !batch->stream || batch->wait_before_walk ||
 	    batch->record_after_walk || batch->n == 0)
-		return enqueue_batch(d, batch);
+		return enqueue_batch(d, batch, sparse);
 	hipStream_t s = (hipStream_t)batch->stream;
-	const acm_dfa::GraphKey key = graph_key(d, batch);
+	const acm_dfa::GraphKey key = graph_key(d, batch, sparse);
 	hipGraphExec_t exec = nullptr;
 	bool capture = false;
 	{
@@ -936,15 +957,15 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 		return ACM_OK;
 	}
 	if (!capture)
-		return enqueue_batch(d, batch);
+		return enqueue_batch(d, batch, sparse);
 	// second sighting: capture.  Argument errors surface here exactly as in the plain path.
 	ACM_HIP_TRY(hipSetDevice(d->device));
 	if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
 		(void)hipGetLastError();
 		d->use_graphs = false;   // e.g. the caller is capturing this stream itself
-		return enqueue_batch(d, batch);
+		return enqueue_batch(d, batch, sparse);
 	}
-	const int rc = enqueue_batch(d, batch);
+	const int rc = enqueue_batch(d, batch, sparse);
 	hipGraph_t graph = nullptr;
 	const hipError_t end = hipStreamEndCapture(s, &graph);
 	if (rc != ACM_OK || end != hipSuccess || !graph) {
@@ -952,14 +973,14 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 			hipGraphDestroy(graph);
 		(void)hipGetLastError();
 		d->use_graphs = false;
-		return rc != ACM_OK ? rc : enqueue_batch(d, batch);
+		return rc != ACM_OK ? rc : enqueue_batch(d, batch, sparse);
 	}
 	const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
 	hipGraphDestroy(graph);
 	if (inst != hipSuccess || !exec) {
 		(void)hipGetLastError();
 		d->use_graphs = false;
-		return enqueue_batch(d, batch);
+		return enqueue_batch(d, batch, sparse);
 	}
 	{
 		std::lock_guard<std::mutex> lock(d->graph_mutex);
@@ -994,7 +1015,7 @@ extern "C" int acm_scan_set_graphs(acm_dfa *d, int enable)
 }
 
 namespace {
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 {
 	const void *d_text = batch->d_text;
 	const size_t n = batch->n, halo = batch->halo;
@@ -1108,12 +1129,13 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch)
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
-	if (use_sparse(d, n)) {
+	if (sparse) {
 		// the walk behind the sparse kernels is an early-exit launch nearly always: keep its LDS
 		// request small, so that placing it does not wait for a CU another stream's filter kernel
 		// (128 KiB of LDS) occupies.  Fewer hot rows only move lookups to the cold plane.
 		a.H = a.H < kFallbackHotRows ? a.H : kFallbackHotRows;
-		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, s, &a.only_if, ev[1], ev[2]);
+		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.misc + 2, s, &a.only_if, ev[1],
+		    ev[2]);
 		if (rc != ACM_OK)
 			return rc;
 	}

@@ -22,7 +22,9 @@ int sparse_prepare(const acm_dfa *d);
 // Enqueue the sparse pipeline for 'b' on stream s.  *gate = device word that is
 // non-zero when the planes were NOT produced and the chain pipeline has to run.
 // after_filter / after_walk: events to record behind the first two kernels, or null.
+// path_marker: device word that receives ACM_SCAN_MODE_SPARSE (the chain kernels overwrite it
+// with 3 when they take over).
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk);
+    uint32_t *path_marker, hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk);
 
 }  // namespace acm

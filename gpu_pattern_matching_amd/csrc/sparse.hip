@@ -101,6 +101,8 @@ struct SparseArgs {
 	uint32_t *block_hits;          // [nblocks] hits the workgroup staged
 	uint2 *hit_list;               // [nblocks][kMaxHits] {position, pattern}, ascending positions
 	uint32_t *flags;               // [0] gave up -> chain pipeline runs
+	uint32_t *path_marker;         // acm_scan_path_taken: set to SPARSE here, overwritten by the chain kernels
+	uint32_t *giveups;             // host-visible count of batches given up on (adaptive AUTO mode), or null
 	unsigned long long *keeper;    // start position << 32 | state of the first walker that reached the end
 	// output
 	int32_t *pat_plane, *off_plane;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 	if (blockIdx.x == 0 && threadIdx.x == 0) {   // first kernel of the pipeline: reset what the others accumulate into
 		a.flags[0] = 0;
 		*a.keeper = ~0ull;
+		*a.path_marker = (uint32_t)ACM_SCAN_MODE_SPARSE;
 	}
 	__syncthreads();
 	const uint32_t word_shift = 32 - a.bloom_log_words;
@@ -454,8 +457,11 @@ __global__ __launch_bounds__(kEmitBlock) void k_sparse_emit(SparseArgs a)
 	__shared__ uint32_t lds[kEmitBlock / 64];
 	__shared__ uint32_t first_cell[kEmitBlock + 1];   // output cell of each workgroup's first kept hit (this pass)
 	__shared__ uint32_t first_kept[kEmitBlock];       // index of that hit in the workgroup's list
-	if (a.flags[0])
-		return;   // a cap was hit: the chain pipeline behind this kernel produces the planes
+	if (a.flags[0]) {   // a cap was hit: the chain pipeline behind this kernel produces the planes
+		if (threadIdx.x == 0 && a.giveups)
+			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return;
+	}
 	uint32_t extent_before = 0, cells_before = 0;   // over the workgroups of earlier passes
 	for (uint32_t first = 0; first < a.nblocks; first += kEmitBlock) {
 		const uint32_t b = first + threadIdx.x;
@@ -547,7 +553,7 @@ int sparse_prepare(const acm_dfa *)
 }
 
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk)
+    uint32_t *path_marker, hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk)
 {
 	const size_t n = b->n;
 	SparseArgs a;
@@ -588,6 +594,8 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	a.pat_plane = b->d_pat_plane;
 	a.off_plane = b->d_off_plane;
 	a.plane_capacity = (uint32_t)(b->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : b->plane_capacity);
+	a.path_marker = path_marker;
+	a.giveups = d->d_giveups;
 	*gate = a.flags;
 
 	// a small filter leaves room for two workgroups per CU (and for the other kernels' LDS)

@@ -237,7 +237,10 @@ int acm_scan_set_graphs(acm_dfa *, int enable);
  *           at least 3 bytes (otherwise CHAIN is used); texts that exceed its
  *           per-walker caps are redone by the chain pipeline inside the same
  *           enqueue, decided on the device
- *   AUTO    SPARSE when the pattern set allows it
+ *   AUTO    SPARSE when the pattern set allows it -- adaptively: a batch the
+ *           sparse kernels give up on costs both pipelines, so when half of
+ *           the last 16 sparse batches ended that way the next 64 go to the
+ *           chain pipeline directly, then the sparse one is tried again
  * Returns the mode in use after the call; acm_scan_mode(d, -1) only queries. */
 enum { ACM_SCAN_MODE_AUTO = 0, ACM_SCAN_MODE_CHAIN = 1, ACM_SCAN_MODE_SPARSE = 2 };
 int acm_scan_set_mode(acm_dfa *, int mode);

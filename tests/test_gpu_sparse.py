@@ -325,3 +325,33 @@ def test_gibibyte_buffer(gpu):
     m.scan(text)
     assert m.path_taken(n) == "sparse"
     m.close()
+
+
+def test_auto_mode_backs_off_when_sparse_keeps_giving_up(gpu):
+    """AUTO: after 16 sparse batches of which at least 8 were given up on (here: all), the next
+    64 go to the chain pipeline directly; then the sparse pipeline is tried again.  Results are
+    the oracle's throughout; a forced SPARSE mode never backs off."""
+    a, o = build(SMALL_SETS["nested"])
+    m = Matcher(a, 0, max_text=1 << 17)
+    endless = np.frombuffer(b"abc" * 40000, dtype=np.uint8)      # one deep run: sparse gives up
+    quiet = np.frombuffer(b"abd" * 40000, dtype=np.uint8)
+    exp_endless, exp_quiet = o.scan(endless), o.scan(quiet)
+    m.set_mode("auto")
+    paths = []
+    for i in range(16 + 64 + 2):
+        assert_same(m.scan(endless), exp_endless)
+        paths.append(m.path_taken(endless.size))
+    assert paths[:16] == ["sparse->chain"] * 16
+    assert paths[16:80] == ["chain"] * 64
+    assert paths[80:] == ["sparse->chain"] * 2                    # trying again
+    m.set_mode("sparse")
+    for i in range(20):
+        assert_same(m.scan(endless), exp_endless)
+        assert m.path_taken(endless.size) == "sparse->chain"
+    m.close()
+    a, o = build(SMALL_SETS["nested"])
+    m = Matcher(a, 0, max_text=1 << 17)                           # a text that never gives up never backs off
+    for i in range(40):
+        assert_same(m.scan(quiet), exp_quiet)
+        assert m.path_taken(quiet.size) == "sparse"
+    m.close()
