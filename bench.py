@@ -14,8 +14,8 @@ flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144
 steps are issued round-robin on --workers HIP streams with private scratch, so the
 latency-bound tail of one batch overlaps the walk of the next.  With N > 1 GPUs the logical
 text is N x 32 MiB, rank g scans shard g (+ an (L-1)-byte halo), the DFA is replicated and
-the compact match planes of every round of --workers steps go to rank 0 in one RCCL gather
-(double-buffered: it overlaps the next round's scans).
+the compact match planes of every group of --gather-rounds x --workers steps go to rank 0 in one
+RCCL gather (double-buffered: it overlaps the next group's scans).
 Weak scaling: 32 MiB per GPU.
 
 Prints ONE JSON line on rank 0.
@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8,
                     help="record the library's HIP events (kernel durations for the roofline) on every K-th "
                          "timed step; those steps are launched kernel by kernel, the others replay the graph")
+    ap.add_argument("--gather-rounds", type=int, default=4,
+                    help="N > 1: rounds of --workers steps whose match planes travel to rank 0 in one gather")
     ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,15 +151,16 @@ def main():
             self.scanned = torch.cuda.Event()       # recorded behind the worker's latest scan
 
     workers = [Worker() for _ in range(W)]
-    # Match planes of one round (W consecutive steps, one per worker) sit in one tensor and travel
-    # to rank 0 in ONE gather: a collective per step would cost more host time than the scan it
-    # follows.  Two such tensors, so the gather of round r overlaps the scans of round r + 1.
-    planes = [torch.zeros((W, 2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [[torch.empty((W, 2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
+    # Match planes of a group of G = --gather-rounds x W consecutive steps sit in one tensor and
+    # travel to rank 0 in ONE gather: a collective per step would cost more host time than the
+    # scan it follows.  Two such tensors, so the gather of one group overlaps the scans of the next.
+    G = W * max(1, args.gather_rounds)
+    planes = [torch.zeros((G, 2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [[torch.empty((G, 2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
                 for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
     gather_stream = torch.cuda.Stream(device=dev)
     gather_done = [None, None]                      # event behind the last gather of each tensor
-    open_round = {"buf": None, "workers": []}       # scans issued but not gathered yet
+    open_group = {"buf": None, "slots": set()}      # scans issued but not gathered yet
     # the walk kernels of consecutive batches are chained by events (batch k+1's walk starts when
     # batch k's walk is done): only the walks serialise, everything behind them overlaps
     walk_done = []
@@ -169,13 +172,13 @@ def main():
     torch.cuda.synchronize()
 
     def flush():
-        """Gather the planes of the round that is open (all of its scans are enqueued)."""
-        buf, ws_ = open_round["buf"], open_round["workers"]
-        open_round["buf"], open_round["workers"] = None, []
+        """Gather the planes of the group that is open (all of its scans are enqueued)."""
+        buf = open_group["buf"]
+        open_group["buf"], open_group["slots"] = None, set()
         if buf is None or world == 1:
             return
         if backend == "nccl":
-            for wk in ws_:
+            for wk in workers:                      # behind every worker's latest scan
                 gather_stream.wait_event(wk.scanned)
             with torch.cuda.stream(gather_stream):
                 dist.gather(planes[buf], gather_list=gathered[buf] if rank == 0 else None, dst=0)
@@ -183,7 +186,7 @@ def main():
                 done.record(gather_stream)
             gather_done[buf] = done
         else:   # rehearsal: through the host
-            for wk in ws_:
+            for wk in workers:
                 wk.stream.synchronize()
             host = planes[buf].cpu()
             bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -193,13 +196,13 @@ def main():
                     g.copy_(h)
 
     def step(k):
-        w, buf = k % W, (k // W) & 1
+        w, buf, slot = k % W, (k // G) & 1, k % G
         wk = workers[w]
-        if open_round["buf"] is not None and (open_round["buf"] != buf or wk in open_round["workers"]):
-            flush()                                 # a new round begins
+        if open_group["buf"] is not None and (open_group["buf"] != buf or slot in open_group["slots"]):
+            flush()                                 # a new group begins
         if gather_done[buf] is not None:            # the gather that last read this tensor:
             wk.stream.wait_event(gather_done[buf])  # the worker's stream waits for it, not the host
-        p = planes[buf][w]
+        p = planes[buf][slot]
         i = issued[0]
         issued[0] += 1
         chain = args.chain_walks and W > 1
@@ -210,9 +213,9 @@ def main():
                            record_after_walk=walk_done[i % len(walk_done)] if chain else None)
         if world > 1:
             wk.scanned.record(wk.stream)
-        open_round["buf"] = buf
-        open_round["workers"].append(wk)
-        if len(open_round["workers"]) == W:
+        open_group["buf"] = buf
+        open_group["slots"].add(slot)
+        if len(open_group["slots"]) == G:
             flush()
 
     def drain():
@@ -265,8 +268,8 @@ def main():
 
     # ---- results of the last step -------------------------------------------------------------
     k_last = max(args.steps - 1, 0)
-    w_last, last = k_last % W, (k_last // W) & 1
-    local = planes[last][w_last].cpu().numpy()
+    slot_last, last = k_last % G, (k_last // G) & 1
+    local = planes[last][slot_last].cpu().numpy()
     m_local = int(local[0, 0])
     m_total = m_local
     if world > 1:
@@ -277,7 +280,7 @@ def main():
     out = None
     if rank == 0:
         if world > 1:
-            offs, pids, last_state = sharding.merge_gathered([g[w_last] for g in gathered[last]])
+            offs, pids, last_state = sharding.merge_gathered([g[slot_last] for g in gathered[last]])
         else:
             offs, pids, last_state = sharding.merge_gathered([local])
         assert offs.size == m_total
