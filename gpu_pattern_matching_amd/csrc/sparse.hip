@@ -79,7 +79,6 @@ constexpr uint32_t kMaxWalkWave = 256;     // walkers per wave (8192 positions)
 constexpr uint32_t kMaxHits = 256;         // staged hits per workgroup (32768 positions)
 
 struct SparseArgs {
-	const uint32_t *cold;
 	const uint64_t *deep;     // [states][256] next | depth(next) << 32 | run(next) << 48
 	const int32_t *out;
 	const uint32_t *dev2ref;
@@ -558,7 +557,6 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	const size_t n = b->n;
 	SparseArgs a;
 	memset(&a, 0, sizeof(a));
-	a.cold = d->d_cold;
 	a.deep = d->d_deep;
 	a.out = b->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
 	a.dev2ref = d->d_dev2ref;
