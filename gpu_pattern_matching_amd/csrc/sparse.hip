@@ -44,7 +44,7 @@
 //
 // The state carried into the buffer (init_state) is handled by a walker at
 // position 0 that starts from it.  Work is capped -- table steps per walker,
-// walkers per 8192 positions, hits per 32768 positions; texts beyond the caps
+// walker rounds per 8192 positions, hits per 32768 positions; texts beyond the caps
 // (one endless deep run, a match at every byte) raise a device flag and the
 // chain pipeline, enqueued right behind and otherwise a row of early-exit
 // launches, produces the planes instead.
@@ -74,8 +74,9 @@ constexpr uint32_t kLaneWords = 2;         // words (of 64 text positions) per l
 constexpr uint32_t kWaveWords = 64 * kLaneWords;             // ... per wave: 8192 positions
 constexpr uint32_t kBlockWords = kWalkWaves * kWaveWords;    // ... per workgroup: 32768 positions
 constexpr uint32_t kIterCap = 256;         // table steps one walker may take ...
+constexpr uint32_t kRunCap = 1024;         // ... or skip this many repeats of one byte in a self-looping state
 constexpr uint32_t kForwardCap = 4096;     // ... each followed by this many fast-forwarded bytes at most
-constexpr uint32_t kMaxWalkWave = 256;     // walkers per wave (8192 positions)
+constexpr uint32_t kMaxWalkWave = 2048;    // walkers per wave (8192 positions): 32 rounds of 64
 constexpr uint32_t kMaxHits = 256;         // staged hits per workgroup (32768 positions)
 
 struct SparseArgs {
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
 struct HitList {
 	uint32_t pos[kMaxHits];
 	uint32_t state[kMaxHits];
-	uint32_t owner[kMaxHits];   // wave << 16 | walker index within the wave; bit 31: dropped
+	uint32_t owner[kMaxHits];   // wave << 16 | round << 8 | lane of the walker; bit 31: dropped
+	int32_t covered[kMaxHits];  // largest deep extent of the wave's walkers in front of that walker
 	uint32_t count;             // may run past kMaxHits: then the workgroup gave up
 };
 
@@ -228,7 +230,30 @@ __device__ __forceinline__ bool walker(const SparseArgs &a, HitList &hits, const
 			reached_end = true;
 			break;
 		}
-		Deep d = deep_step(a, state, txt.at(p - tbase + 1));
+		const uint32_t byte = txt.at(p - tbase + 1);
+		Deep d = deep_step(a, state, byte);
+		if (d.s == state && d.depth >= 3 && state < a.F) {
+			// A deep, non-final state that maps to itself: the text repeats one byte (a zero page
+			// under a signature that starts with zeros) and nothing changes until it stops doing
+			// so.  Skip the repeats 16 per load level; past kRunCap bytes the run is the chain
+			// pipeline's job (it does not care how long a run is).
+			const uint64_t splat = 0x0101010101010101ull * byte;
+			uint32_t skipped = 0;
+			while (p + 17 <= a.n && skipped < kRunCap) {
+				const acm_dev::Unaligned16 *t = (const acm_dev::Unaligned16 *)(a.text + p + 1);
+				const uint64_t x0 = t->lo ^ splat, x1 = t->hi ^ splat;
+				const uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
+							 : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
+				p += same;
+				skipped += same;
+				if (same < 16)
+					break;
+			}
+			if (skipped >= kRunCap) {
+				ok = false;
+				break;
+			}
+		}
 		state = d.s;
 		const bool deep = d.depth >= 3;
 		if (deep)
@@ -277,10 +302,11 @@ __global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 {
 	__shared__ HitList hits;
 	__shared__ uint64_t lmask[kWalkWaves][kWaveWords];       // candidate bits of the wave's words
-	__shared__ int32_t walker_m[kWalkWaves][kMaxWalkWave];   // max deep extent of the wave's walkers before k
 	__shared__ int32_t wave_max[kWalkWaves];
 	__shared__ uint32_t s_gave_up, s_survivors;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	static_assert(kMaxHits == kWalkBlock, "one thread clears one slot");
+	hits.owner[threadIdx.x] = 0xFFFFFFFFu;   // a reserved but not yet written slot belongs to nobody
 	if (threadIdx.x == 0) {
 		hits.count = 0;
 		s_gave_up = 0;
@@ -319,8 +345,11 @@ __global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 	const uint32_t total = __shfl(inc, 63, 64), base = inc - cnt;
 	bool ok = total <= kMaxWalkWave;   // wave-uniform
 	int32_t carry = -1;                // largest deep extent of the wave's walkers so far
+	uint32_t settled = 0;              // hits below this index have their 'covered' value
 	const uint32_t rounds = ok ? (total + 63) / 64 : 0;
 	for (uint32_t r = 0; r < rounds; r++) {   // walker k runs on lane k % 64, whichever word it starts in
+		if (__any(*(volatile uint32_t *)a.flags != 0))
+			break;   // some walker of the batch hit a cap: the chain pipeline will redo it all
 		const uint32_t k = r * 64 + lane;
 		const bool valid = k < total;
 		uint32_t owner_lane = 0;               // the last lane whose first walker index is <= k
@@ -357,7 +386,9 @@ __global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 				word_starts &= word_starts - 1;
 			const uint32_t p0 = ((word0 + owner_lane * kLaneWords + word_index) << 6) +
 					    (uint32_t)__ffsll((long long)word_starts) - 1;
-			ok &= walker(a, hits, lmask[wv], word0, (wv << 16) | k, p0, end);
+			ok &= walker(a, hits, lmask[wv], word0, (wv << 16) | (r << 8) | lane, p0, end);
+			if (!ok)
+				a.flags[0] = 1;   // at once: every wave of the batch stops at its next round
 		}
 		int32_t incm = end;   // inclusive prefix max over the round, then exclusive + earlier rounds
 #pragma unroll
@@ -369,8 +400,17 @@ __global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 		int32_t excl = __shfl_up(incm, 1, 64);
 		if (lane == 0)
 			excl = -1;
-		if (valid)
-			walker_m[wv][k] = max(carry, excl);
+		// the hits this round's walkers staged learn what the walkers in front of theirs cover
+		// (the value sits in the owner's lane: a shuffle, in a loop every lane runs)
+		const int32_t before = max(carry, excl);
+		const uint32_t staged = min(*(volatile uint32_t *)&hits.count, kMaxHits);
+		for (uint32_t i = settled; i < staged; i++) {
+			const uint32_t o = *(volatile uint32_t *)&hits.owner[i];
+			const int32_t v = __shfl(before, o & 63u, 64);
+			if (lane == 0 && (o >> 8) == ((wv << 8) | r))
+				hits.covered[i] = v;
+		}
+		settled = staged;
 		carry = max(carry, __shfl(incm, 63, 64));
 	}
 	if (!ok)
@@ -383,7 +423,7 @@ __global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
 	const uint32_t nh = min(hits.count, kMaxHits);
 	for (uint32_t i = threadIdx.x; i < nh; i += kWalkBlock) {
 		const uint32_t o = hits.owner[i], ow = o >> 16;
-		int32_t m = walker_m[ow][o & 0xFFFFu];
+		int32_t m = hits.covered[i];
 		for (uint32_t v = 0; v < ow; v++)
 			m = max(m, wave_max[v]);
 		if ((int32_t)hits.pos[i] <= m)

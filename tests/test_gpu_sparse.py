@@ -355,3 +355,40 @@ def test_auto_mode_backs_off_when_sparse_keeps_giving_up(gpu):
         assert_same(m.scan(quiet), exp_quiet)
         assert m.path_taken(quiet.size) == "sparse"
     m.close()
+
+
+def test_real_binary_content(gpu):
+    """Not synthetic: 48 MiB out of the middle of the largest ROCm library on the box (code, zero
+    pages, tables, strings) x 2000 and 15000 signatures.  Whatever path the data makes the sparse
+    pipeline take, piece by piece, the planes are the oracle's."""
+    import glob
+    import os
+    libs = sorted(glob.glob("/opt/rocm/lib/*.so*"), key=lambda f: os.path.getsize(f) if os.path.isfile(f) else 0)
+    if not libs or os.path.getsize(libs[-1]) < (64 << 20):
+        pytest.skip("no large library to read")
+    size = os.path.getsize(libs[-1])
+    with open(libs[-1], "rb") as fh:
+        fh.seek((size // 2) & ~4095)
+        data = np.frombuffer(fh.read(48 << 20), dtype=np.uint8)
+    for name in ("clamav2000", "clamav15000"):
+        o = fixtures.oracle_for(name)
+        path, hx, ml = fixtures.set_source(name)
+        a = Automaton()
+        a.load_file(path, hx, ml)
+        a.compile()
+        m = Matcher(a, 0, max_text=16 << 20, plane_capacity=1 << 22)
+        a.close()
+        state, paths = 0, []
+        for mode in ("auto", "sparse"):
+            m.set_mode(mode)
+            state = 0
+            for at in range(0, data.size, 16 << 20):      # streamed in 16 MiB pieces, state carried
+                piece = data[at:at + (16 << 20)]
+                exp = o.scan(piece, state, cap=1 << 22)
+                got = m.scan(piece, state)
+                assert_same(got, exp)
+                paths.append(m.path_taken(piece.size))
+                state = exp[2]
+        assert set(paths) <= {"sparse", "sparse->chain", "chain"}
+        print(name, os.path.basename(libs[-1]), paths)
+        m.close()
