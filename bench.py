@@ -331,7 +331,7 @@ def main():
         if path == "chain":
             kernels = [("k_spec_walk", k1_ms, solo_k1_ms)]
         else:
-            kernels = [("k_sparse_filter", k1_ms, solo_k1_ms), ("k_sparse_walk", k2_ms, solo_k2_ms)]
+            kernels = [("k_sieve", k1_ms, solo_k1_ms), ("k_sieve_emit", k2_ms, solo_k2_ms)]
         kname, kms, ksolo_ms = max(kernels, key=lambda t: t[1])
         walk_s = kms / 1e3 / L1
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0

@@ -184,7 +184,7 @@ class Matcher:
         return self.lib.acm_scan_set_chains_per_lane(self.dfa, c)
 
     MODES = {"auto": 0, "chain": 1, "sparse": 2}
-    PATHS = {1: "chain", 2: "sparse", 3: "sparse->chain"}
+    PATHS = {1: "chain", 2: "sparse", 0xDEAD: "failed"}
 
     def set_mode(self, mode):
         """'auto' | 'chain' | 'sparse' (acm_scan_set_mode); returns the mode in use."""

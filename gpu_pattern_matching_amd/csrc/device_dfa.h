@@ -23,13 +23,25 @@ struct acm_dfa {
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
 	uint8_t *d_in_byte = nullptr;        // [states + 96] byte on the edge into dev state
-	uint32_t *d_bloom = nullptr;         // [1 << bloom_log_words] trigrams of the depth-3 states (sparse pipeline)
-	uint32_t bloom_log_words = 15;
-	uint32_t *d_t2g = nullptr;           // [65536] state after bytes (p, c) from the root, index p | c << 8
+	uint16_t *d_depth = nullptr;         // [states] trie depth of each state (carried-state walker of the sparse pipeline)
+
+	// sparse ("sieve") pipeline tables, sieve_tables.h
+	uint32_t sv_stride = 0;              // W: one text position in W is sampled
+	uint32_t sv_prefix_len = 0;          // D: bytes of a pattern checked exactly before a follower starts
+	uint32_t *d_sv_bloom = nullptr;      // [1 << sv_bloom_log_words] Bloom filter over the 3-grams at offsets < W, copied to LDS
+	uint32_t sv_bloom_log_words = 0;
+	uint32_t *d_sv_gram = nullptr;       // [4 << sv_gram_log_buckets] gram | offset mask << 24, four per bucket
+	uint32_t sv_gram_log_buckets = 0, sv_gram_probes = 1;
+	uint32_t *d_sv_prefix = nullptr;     // [4 << sv_prefix_log_slots] 16-byte slots: key, run, node
+	uint32_t sv_prefix_log_slots = 0, sv_prefix_probes = 1;
+	void *d_sv_rec = nullptr;            // [states] node records (acm::SieveRec, 16 bytes)
+	void *d_sv_edges = nullptr;          // edges of the nodes with two or more children
 	uint32_t *d_list_begin = nullptr;    // [states, reference numbering] offset of the state's match list in d_list_pool
 	uint32_t *d_list_len = nullptr;      // [states] its length (0: not final)
 	int32_t *d_list_pool = nullptr;      // pattern indices, list order
 	size_t device_bytes = 0;
+	void *arena = nullptr;               // one allocation for the small tables (device_dfa.hip, upload_small)
+	size_t arena_bytes = 0, arena_used = 0;
 
 	// adaptive AUTO mode (scan.hip, pick_sparse): batches the sparse kernels gave up on, counted by
 	// the device in pinned host memory

@@ -31,11 +31,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <unordered_map>
 
 #include "acm_internal.h"
 #include "device_dfa.h"
+#include "sieve_tables.h"
 #include "sparse.h"
 
 extern "C" int acm_device_count(void)
@@ -57,6 +60,160 @@ int upload(T **dptr, const T *src, size_t count, size_t *total)
 		ACM_HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
 	*total += bytes;
 	return ACM_OK;
+}
+
+// The small tables the latency-bound lookups touch (node records, hash tables, per-state
+// arrays) share ONE allocation: a lookup that lands on a page nobody touched lately pays an
+// address translation on top of the access, and separate hipMallocs are separate small pages.
+template <typename T>
+int upload_small(acm_dfa *d, T **dptr, const T *src, size_t count)
+{
+	const size_t bytes = ((count ? count : 1) * sizeof(T) + 255) & ~(size_t)255;
+	if (d->arena && d->arena_used + bytes <= d->arena_bytes) {
+		*dptr = (T *)((char *)d->arena + d->arena_used);
+		d->arena_used += bytes;
+		if (count)
+			ACM_HIP_TRY(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+		return ACM_OK;
+	}
+	return upload(dptr, src, count, &d->device_bytes);
+}
+
+void free_small(acm_dfa *d, void *p)
+{
+	if (p && !(d->arena && (char *)p >= (char *)d->arena && (char *)p < (char *)d->arena + d->arena_bytes))
+		hipFree(p);
+}
+
+// Tables of the sparse pipeline (sieve_tables.h).  sparse_ok stays false for sets the
+// pipeline does not apply to (a pattern shorter than 3 bytes, or none at all).
+int build_sieve(const acm_automaton &a, acm_dfa *d)
+{
+	d->sparse_ok = false;
+	size_t shortest = SIZE_MAX;
+	for (const auto &p : a.patterns)
+		shortest = std::min(shortest, p.bytes.size());
+	if (a.patterns.empty() || shortest < 3)
+		return ACM_OK;
+	const uint32_t n = a.num_states, F = a.first_final;
+	const uint32_t W = acm::sieve_stride((uint32_t)std::min<size_t>(shortest, 64));
+	const uint32_t D = (uint32_t)std::min<size_t>(shortest, acm::kSieveMaxPrefix);
+	d->sv_stride = W;
+	d->sv_prefix_len = D;
+
+	// 3-grams at offsets < W of every pattern, with the offsets they occur at
+	std::unordered_map<uint32_t, uint32_t> grams;
+	grams.reserve(a.patterns.size() * W * 2);
+	for (const auto &p : a.patterns)
+		for (uint32_t o = 0; o < W; o++) {
+			const uint32_t g = (uint32_t)p.bytes[o] | ((uint32_t)p.bytes[o + 1] << 8) | ((uint32_t)p.bytes[o + 2] << 16);
+			grams[g] |= 1u << o;
+		}
+	uint32_t lw = acm::kSieveMinLogWords;
+	while (lw < acm::kSieveMaxLogWords && ((size_t)1 << lw) < grams.size())
+		lw++;
+	if (const char *e = getenv("ACM_BLOOM_LOG_WORDS")) {   // debugging aid
+		const int v = atoi(e);
+		if (v >= (int)acm::kSieveMinLogWords && v <= (int)acm::kSieveMaxLogWords)
+			lw = (uint32_t)v;
+	}
+	d->sv_bloom_log_words = lw;
+	std::vector<uint32_t> bloom((size_t)1 << lw, 0);
+	for (const auto &kv : grams)
+		bloom[acm::sieve_bloom_word(kv.first, lw)] |= acm::sieve_bloom_bits(kv.first);
+
+	// gram table: buckets of four, one gram per bucket on average (a full bucket costs the
+	// lookup a second, dependent load: 2 % of the buckets)
+	uint32_t lb = 4;
+	while (((size_t)1 << lb) < grams.size())
+		lb++;
+	std::vector<uint32_t> gt((size_t)4 << lb, 0);
+	uint32_t gprobes = 1;
+	for (const auto &kv : grams) {
+		uint32_t b = acm::sieve_gram_bucket(kv.first, lb), probes = 1;
+		for (;; b = (b + 1) & ((1u << lb) - 1), probes++) {
+			uint32_t *slot = &gt[(size_t)b * 4];
+			int k = 0;
+			while (k < 4 && slot[k] != 0)
+				k++;
+			if (k < 4) {
+				slot[k] = kv.first | (kv.second << 24);
+				break;
+			}
+		}
+		gprobes = std::max(gprobes, probes);
+	}
+	d->sv_gram_log_buckets = lb;
+	d->sv_gram_probes = gprobes;
+
+	// prefix table: every depth-D node under its D path bytes
+	std::vector<uint32_t> nodes;
+	for (uint32_t r = 0; r < n; r++)
+		if (a.depth[r] == D)
+			nodes.push_back(r);
+	uint32_t ls = 4;   // an eighth full: a lookup ends at the first slot it reads, nearly always
+	while (((size_t)1 << ls) < 8 * nodes.size())
+		ls++;
+	std::vector<uint32_t> pt((size_t)4 << ls, 0);
+	uint32_t pprobes = 1;
+	for (uint32_t r : nodes) {
+		uint8_t key[12] = { 0 };
+		uint32_t s = r;
+		for (uint32_t k = D; k-- > 0; s = a.parent[s])
+			key[k] = a.in_byte[s];
+		uint32_t k0, k1, k2;
+		memcpy(&k0, key, 4);
+		memcpy(&k1, key + 4, 4);
+		memcpy(&k2, key + 8, 4);
+		const uint32_t dev = a.ref2dev[r];
+		uint32_t at = acm::sieve_prefix_slot(k0, k1, k2, ls), probes = 1;
+		while (pt[(size_t)at * 4 + 3] != 0) {
+			at = (at + 1) & ((1u << ls) - 1);
+			probes++;
+		}
+		pt[(size_t)at * 4 + 0] = k0;
+		pt[(size_t)at * 4 + 1] = k1;
+		pt[(size_t)at * 4 + 2] = k2 | ((uint32_t)a.dev_run[dev] << 16);
+		pt[(size_t)at * 4 + 3] = dev;
+		pprobes = std::max(pprobes, probes);
+	}
+	d->sv_prefix_log_slots = ls;
+	d->sv_prefix_probes = pprobes;
+
+	// node records and edges
+	std::vector<acm::SieveRec> rec(n, acm::sieve_rec(0, 0, 0, false, 0, 0, 0)), edges;
+	for (uint32_t dev = 0; dev < n; dev++) {
+		const uint32_t r = a.dev2ref[dev];
+		const uint32_t cb = a.child_begin[r], ce = a.child_begin[r + 1], nc = ce - cb;
+		auto leaf = [&](uint32_t child_ref) { return a.child_begin[child_ref + 1] == a.child_begin[child_ref]; };
+		auto outp = [&](uint32_t child_ref) { return a.is_final_ref(child_ref) ? (uint32_t)a.head_of(child_ref) : 0xFFFFFFFFu; };
+		if (nc == 1) {
+			const uint32_t c = a.child_list[cb].to, cd = a.ref2dev[c];
+			rec[dev] = acm::sieve_rec(cd, a.child_list[cb].byte, 1, leaf(c), a.dev_run[cd], outp(c), c);
+		} else if (nc >= 2) {
+			rec[dev] = acm::sieve_rec((uint32_t)edges.size(), 0, nc, false, 0, 0, 0);
+			for (uint32_t e = cb; e < ce; e++) {
+				const uint32_t c = a.child_list[e].to, cd = a.ref2dev[c];
+				edges.push_back(acm::sieve_edge(a.child_list[e].byte, cd, leaf(c), a.dev_run[cd], outp(c), c));
+			}
+		}
+	}
+	if (edges.size() >= (1u << 24))
+		return ACM_OK;   // edge index does not fit a record: the set stays on the chain pipeline
+	edges.push_back(acm::sieve_edge(0, 0, false, 0, 0, 0));
+	(void)F;
+
+	int rc = upload_small(d, &d->d_sv_bloom, bloom.data(), bloom.size());
+	if (rc == ACM_OK) rc = upload_small(d, &d->d_sv_gram, gt.data(), gt.size());
+	if (rc == ACM_OK) rc = upload_small(d, &d->d_sv_prefix, pt.data(), pt.size());
+	acm::SieveRec *drec = nullptr, *dedges = nullptr;
+	if (rc == ACM_OK) rc = upload_small(d, &drec, rec.data(), rec.size());
+	if (rc == ACM_OK) rc = upload_small(d, &dedges, edges.data(), edges.size());
+	d->d_sv_rec = drec;
+	d->d_sv_edges = dedges;
+	if (rc == ACM_OK)
+		d->sparse_ok = true;
+	return rc;
 }
 
 }  // namespace
@@ -84,6 +241,16 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 	d->ref2dev = a->ref2dev;
 
 	int rc = ACM_OK;
+	{
+		const size_t want = (((size_t)a->num_states * 48 + (8u << 20)) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+		if (hipMalloc(&d->arena, want) == hipSuccess) {
+			d->arena_bytes = want;
+			d->device_bytes += want;
+		} else {
+			d->arena = nullptr;
+			(void)hipGetLastError();
+		}
+	}
 	try {
 		const std::vector<uint64_t> &rows = a->dense_rows();
 		const uint32_t n = a->num_states, H = a->hot_count, F = a->first_final;
@@ -109,38 +276,19 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 				rc = upload(&d->d_deep, rows.data(), rows.size(), &d->device_bytes);
 		}
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_out, outp.data(), outp.size(), &d->device_bytes);
+		if (rc == ACM_OK) rc = upload_small(d, &d->d_out, outp.data(), outp.size());
 		if (rc == ACM_OK)
-			rc = upload(&d->d_dev2ref, a->dev2ref.data(), a->dev2ref.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_in_byte, inb.data(), inb.size(), &d->device_bytes);
+			rc = upload_small(d, &d->d_dev2ref, a->dev2ref.data(), a->dev2ref.size());
+		if (rc == ACM_OK) rc = upload_small(d, &d->d_in_byte, inb.data(), inb.size());
 
-		// sparse pipeline: Bloom filter over the byte triples that lead to a
-		// depth-3 state, and the depth <= 2 part of the DFA as a flat table
-		std::vector<uint32_t> tris, t2g(65536);
-		for (uint32_t s = 0; s < n; s++) {
-			const uint32_t r2 = a->dev2ref[s];
-			if (a->depth[r2] != 3)
-				continue;
-			const uint32_t r1 = a->parent[r2], r0 = a->parent[r1];
-			tris.push_back((uint32_t)a->in_byte[r0] | ((uint32_t)a->in_byte[r1] << 8) |
-			    ((uint32_t)a->in_byte[r2] << 16));
+		if (rc == ACM_OK) {
+			std::vector<uint16_t> dep(n);
+			for (uint32_t s = 0; s < n; s++)
+				dep[s] = a->depth[a->dev2ref[s]];
+			rc = upload_small(d, &d->d_depth, dep.data(), dep.size());
 		}
-		d->bloom_log_words = acm::kBloomMinLogWords;
-		while (d->bloom_log_words < acm::kBloomMaxLogWords && ((size_t)1 << d->bloom_log_words) < 4 * tris.size())
-			d->bloom_log_words++;
-		if (const char *e = getenv("ACM_BLOOM_LOG_WORDS")) {   // debugging aid
-			const int v = atoi(e);
-			if (v >= (int)acm::kBloomMinLogWords && v <= (int)acm::kBloomMaxLogWords)
-				d->bloom_log_words = (uint32_t)v;
-		}
-		std::vector<uint32_t> bloom((size_t)1 << d->bloom_log_words, 0);
-		for (uint32_t tri : tris)
-			bloom[acm::bloom_word(tri, d->bloom_log_words)] |= acm::bloom_bits(tri);
-		for (uint32_t p = 0; p < 256; p++) {
-			const uint32_t s1 = (uint32_t)rows[p];
-			for (uint32_t c = 0; c < 256; c++)
-				t2g[p | (c << 8)] = (uint32_t)rows[(size_t)s1 * 256 + c];
-		}
+		if (rc == ACM_OK)
+			rc = build_sieve(*a, d);
 		// match lists, for all-patterns reporting (post.hip, acm_expand_matches_async)
 		std::vector<uint32_t> lbegin(n, 0), llen(n, 0);
 		for (uint32_t r = 0; r < n; r++)
@@ -151,12 +299,6 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		if (rc == ACM_OK) rc = upload(&d->d_list_begin, lbegin.data(), lbegin.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_list_len, llen.data(), llen.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload(&d->d_list_pool, a->list_pool.data(), a->list_pool.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_bloom, bloom.data(), bloom.size(), &d->device_bytes);
-		if (rc == ACM_OK) rc = upload(&d->d_t2g, t2g.data(), t2g.size(), &d->device_bytes);
-		d->sparse_ok = !a->patterns.empty();
-		for (const auto &p : a->patterns)
-			if (p.bytes.size() < 3)
-				d->sparse_ok = false;
 	} catch (const std::bad_alloc &) {
 		rc = acm::fail(ACM_ERR_NOMEM, "acm_dfa_upload: out of host memory");
 	}
@@ -199,14 +341,19 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_cold);
 		hipFree(d->d_deep);
 		hipFree(d->d_hot);
-		hipFree(d->d_out);
-		hipFree(d->d_dev2ref);
-		hipFree(d->d_in_byte);
+		free_small(d, d->d_out);
+		free_small(d, d->d_dev2ref);
+		free_small(d, d->d_in_byte);
 		hipFree(d->d_list_begin);
 		hipFree(d->d_list_len);
 		hipFree(d->d_list_pool);
-		hipFree(d->d_bloom);
-		hipFree(d->d_t2g);
+		free_small(d, d->d_depth);
+		free_small(d, d->d_sv_bloom);
+		free_small(d, d->d_sv_gram);
+		free_small(d, d->d_sv_prefix);
+		free_small(d, d->d_sv_rec);
+		free_small(d, d->d_sv_edges);
+		hipFree(d->arena);
 		if (d->h_giveups)
 			hipHostFree(d->h_giveups);
 		for (auto &g : d->graphs)

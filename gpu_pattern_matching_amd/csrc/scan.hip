@@ -68,7 +68,6 @@ constexpr int kBlock1 = 1024;          // K1 workgroup: 16 waves, one per CU (LD
 constexpr int kWaves1 = kBlock1 / 64;
 constexpr int kBlock2 = 256;
 constexpr uint32_t kNoFirst = 0xFFFFu;
-constexpr uint32_t kFallbackHotRows = 32;   // LDS rows of the walk when it is the sparse pipeline's fallback
 constexpr uint8_t kProbeTodo = 0xFF;
 
 struct ScanArgs {
@@ -111,7 +110,6 @@ struct ScanArgs {
 	int32_t *pat_plane;
 	int32_t *off_plane;
 	uint32_t plane_capacity;
-	const uint32_t *only_if;   // when set: run only if this device word is non-zero
 	uint32_t fold_blocks;      // > 0: off[] holds the raw totals of this many blocks; the scatter adds them up itself
 };
 
@@ -330,8 +328,6 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 template <int C>
 __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 {
-	if (a.only_if && *a.only_if == 0)
-		return;   // the sparse pipeline already produced the planes
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
 	{
 		// every workgroup copies the same table: start each one at a different
@@ -373,8 +369,6 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 // Chains the walk kernel's epilogue already probed are skipped.
 __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 {
-	if (a.only_if && *a.only_if == 0)
-		return;   // the sparse pipeline already produced the planes
 	const uint32_t c = blockIdx.x * kBlock2 + threadIdx.x;
 	if (c >= a.n_chains)
 		return;
@@ -410,8 +404,6 @@ __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 // K2b resolve: one lane per chain (see the file header).
 __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 {
-	if (a.only_if && *a.only_if == 0)
-		return;   // the sparse pipeline already produced the planes
 	__shared__ uint32_t wave_fill[kBlock2 / 64];
 	__shared__ uint32_t wave_sum[kBlock2 / 64];
 	const uint32_t j = blockIdx.x * kBlock2 + threadIdx.x;
@@ -547,8 +539,6 @@ constexpr uint32_t kFoldMax = 8192;   // block totals a scatter block still adds
 
 __global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t nb)
 {
-	if (a.only_if && *a.only_if == 0)
-		return;   // the sparse pipeline already produced the planes
 	__shared__ int32_t tree[kTopThreads + (kTopThreads >> 5) + 1];
 	const int tid = threadIdx.x;
 	const uint32_t per = (nb + kTopThreads - 1) / kTopThreads;
@@ -596,8 +586,6 @@ __global__ __launch_bounds__(kTopThreads) void k_scan_top(ScanArgs a, uint32_t n
 template <int C>
 __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 {
-	if (a.only_if && *a.only_if == 0)
-		return;   // the sparse pipeline already produced the planes
 	__shared__ uint32_t off[kBlock2];
 	__shared__ uint32_t wtot[kBlock2 / 64];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -681,7 +669,7 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 	if (blockIdx.x == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
 		const uint32_t total = total_records;
 		const int32_t last_ref = (int32_t)a.dev2ref[a.misc[0]];
-		a.misc[2] = a.only_if ? 3u : (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
+		a.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
 		uint32_t tail = total + 1;
 		if (tail > a.plane_capacity - 1)
 			tail = a.plane_capacity - 1;
@@ -719,7 +707,7 @@ struct Layout {
 };
 
 // sized for the smallest chain length (16 B) so any geometry fits
-Layout layout_for(size_t max_text)
+Layout layout_for(const acm_dfa *d, size_t max_text)
 {
 	Layout l;
 	const size_t chains = max_text / 16 + 64 * 4 + 64;
@@ -746,7 +734,7 @@ Layout layout_for(size_t max_text)
 	l.stage2 = take(stage_recs * 8);
 	l.scan_ws_bytes = acm_exclusive_scan_workspace_bytes(chains / kBlock2 + 2);
 	l.scan_ws = take(l.scan_ws_bytes);
-	l.sparse = take(acm::sparse_workspace_bytes(max_text));
+	l.sparse = take(d ? acm::sparse_workspace_bytes(d, max_text) : 0);
 	l.total = o;
 	return l;
 }
@@ -765,9 +753,9 @@ int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 
 }  // namespace
 
-extern "C" size_t acm_scan_workspace_bytes(const acm_dfa *, size_t max_text)
+extern "C" size_t acm_scan_workspace_bytes(const acm_dfa *d, size_t max_text)
 {
-	return layout_for(max_text).total;
+	return layout_for(d, max_text).total;
 }
 
 extern "C" int acm_scan_set_chain_bytes(acm_dfa *d, int chain_bytes)
@@ -836,7 +824,7 @@ extern "C" int acm_scan_path_taken(const acm_dfa *d, const void *d_workspace, si
 	ACM_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
 	if (n == 0)
 		return ACM_SCAN_MODE_CHAIN;
-	const Layout l = layout_for(n);
+	const Layout l = layout_for(d, n);
 	uint32_t marker = 0;   // misc[2]: written by whichever pipeline produced the planes
 	ACM_HIP_TRY(hipMemcpy(&marker, (const char *)d_workspace + l.misc + 8, 4, hipMemcpyDeviceToHost));
 	return (int)marker;
@@ -1040,7 +1028,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: init_state %ld is not a state", init_state);
 	if (plane_capacity > 0xFFFFFFFFul)
 		plane_capacity = 0xFFFFFFFFul;
-	const Layout l = layout_for(n);
+	const Layout l = layout_for(d, n);
 	if (!d_workspace || workspace_bytes < l.total)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: workspace %zu B < required %zu B",
 		    workspace_bytes, l.total);
@@ -1129,22 +1117,25 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 	if (d->profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
-	if (sparse) {
-		// the walk behind the sparse kernels is an early-exit launch nearly always: keep its LDS
-		// request small, so that placing it does not wait for a CU another stream's filter kernel
-		// (128 KiB of LDS) occupies.  Fewer hot rows only move lookups to the cold plane.
-		a.H = a.H < kFallbackHotRows ? a.H : kFallbackHotRows;
-		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.misc + 2, s, &a.only_if, ev[1],
-		    ev[2]);
+	if (sparse) {   // three kernels of its own; it always produces the planes
+		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.misc + 2, s, ev[1], ev[2]);
 		if (rc != ACM_OK)
 			return rc;
+		if (batch->record_after_walk)
+			ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
+		if (d->profile) {
+			ACM_HIP_TRY(hipEventRecord(ev[3], s));
+			for (auto e : ev)
+				d->profile_events.push_back((void *)e);
+		}
+		return ACM_OK;
 	}
 	rc = C == 4 ? launch_spec_walk<4>(a, d->num_cus, s) : launch_spec_walk<2>(a, d->num_cus, s);
 	if (rc != ACM_OK)
 		return rc;
 	if (batch->record_after_walk)
 		ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
-	if (d->profile && !a.only_if) {   // chain pipeline on its own: the walk is the first stage, no second
+	if (d->profile) {   // the walk is the first stage, there is no second
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
 		ACM_HIP_TRY(hipEventRecord(ev[2], s));
 	}

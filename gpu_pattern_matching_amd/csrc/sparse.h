@@ -13,18 +13,17 @@ struct acm_dfa;
 namespace acm {
 
 // bytes of private workspace the sparse pipeline needs for texts up to max_text
-size_t sparse_workspace_bytes(size_t max_text);
+size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text);
 
 // once per device DFA: kernel attributes (scan.hip / sparse.hip)
 int scan_prepare(const acm_dfa *d);
 int sparse_prepare(const acm_dfa *d);
 
-// Enqueue the sparse pipeline for 'b' on stream s.  *gate = device word that is
-// non-zero when the planes were NOT produced and the chain pipeline has to run.
-// after_filter / after_walk: events to record behind the first two kernels, or null.
+// Enqueue the sparse pipeline for 'b' on stream s (three kernels; it always produces the planes).
+// after_sieve / after_emit: events to record behind the two kernels, or null.
 // path_marker: device word that receives ACM_SCAN_MODE_SPARSE (the chain kernels overwrite it
 // with 3 when they take over).
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    uint32_t *path_marker, hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk);
+    uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit);
 
 }  // namespace acm

@@ -1,56 +1,61 @@
-// The sparse scan pipeline: trigram filter -> candidate walks with in-kernel
-// dedup, count and ordered scatter.  gfx950 only.  Same contract and output as
+// The sparse ("sieve") scan pipeline: strided 3-gram filter -> exact prefix check ->
+// trie-path followers -> ordered emit.  gfx950 only.  Same contract and output as
 // the chain pipeline of scan.hip (it is the second implementation of
-// acm_scan_*_async, chosen for pattern sets whose shortest pattern has at
-// least 3 bytes); scan.hip stays the general path and the in-enqueue fallback.
+// acm_scan_*_async, for pattern sets whose shortest pattern has at least 3
+// bytes); scan.hip stays the general path and the in-enqueue fallback.
 //
-// Why it is exact.  The serial DFA state at text position k is the longest
-// suffix of the text that is a trie node.  While that depth is <= 2 the state
-// is a pure function of the last two bytes (T2).  Depth can only grow by one
-// per byte, so every maximal stretch of positions with depth >= 3 (a "deep
-// run") starts at a position whose last three bytes ARE a depth-3 trie node.
-// With patterns of >= 3 bytes every final state has depth >= 3: all records
-// lie inside deep runs.  So:
+// Why it is exact.  The serial DFA state at text position e is the longest suffix
+// of the text that is a trie node; call its first byte the START of e.  Let m be
+// the length of the shortest pattern, W the stride (sieve_tables.h: W + 2 <= m)
+// and D = min(m, 10).  Every final state has depth >= m >= D, so a record at e
+// lies on a trie path text[s..e] of at least D bytes, s = start(e).
 //
-//   SF  k_sparse_filter   every position tests its trigram against a Bloom
-//                         filter of the depth-3 nodes held in LDS (no false
-//                         negatives).  No state, no dependent load, fully
-//                         coalesced text reads: this is the bulk pass.
-//                         Output: one candidate bit per text byte.
-//   SW  k_sparse_walk     one walker per run of consecutive candidate bits:
-//                         start in T2[bytes a-2, a-1] at position a and walk
-//                         the DFA exactly (deep plane, fast-forward)
-//                         while the state is deep or the next position is a
-//                         candidate.  A walker that started while an earlier
-//                         deep run was still alive walks suffix-states of the
-//                         true ones until that run ends, and exact states
-//                         after it.  Hence the rule: walker j keeps its hits
-//                         at positions > M_j, the largest deep extent of the
-//                         walkers before it in position order -- exactly the
-//                         part of its walk no earlier walker covers.  M_j is
-//                         an exclusive prefix max; the part of it inside the
-//                         workgroup (shuffles within a wave, LDS across
-//                         waves) is applied here.  Hits stay in LDS while the
-//                         walkers run (on gfx9 a store in flight holds up the
-//                         next dependent load); at the end the workgroup
-//                         writes its surviving hits in position order and its
-//                         largest deep extent.
-//   SE  k_sparse_emit     one workgroup: prefix max of the workgroup extents,
-//                         drops the hits an earlier workgroup's walker covers
-//                         (a prefix of each sorted list), prefix sum of what
-//                         is left, ordered scatter into the planes, header
-//                         and trailer cells.  A few thousand values: latency,
-//                         not bandwidth.
+//  1. Sieve.  The path's first W + 2 bytes are the first W + 2 bytes of a pattern.
+//     The one sample position p = 0 mod W in [s, s + W) sees the 3-gram
+//     P[p-s .. p-s+2], which is in G = { P[o..o+2] : o < W }.  Testing only the
+//     samples against G (a Bloom filter in LDS, no false negatives) therefore
+//     misses no start: one LDS probe per W text bytes, everything else about the
+//     bulk pass is the coalesced 16 B/lane read of the text -- HBM roofline.
+//  2. Check.  A flagged sample asks the exact gram table for the offsets o its
+//     3-gram occurs at, and the prefix table whether text[p-o .. p-o+D) is a trie
+//     path: what survives is a FOLLOWER (s, depth-D node).
+//  3. Follow.  A follower walks its own path only: compare the text with the
+//     single outgoing edge (16 bytes per load along unary runs) or pick the child
+//     from a short edge list; the first mismatch ends it.  No fail links: the
+//     suffix the DFA would fall back to starts later and has its own follower.
+//     extent(s) = last position its path reaches.  It notes the final nodes it
+//     enters as hits.
+//  4. Shadow.  Followers alive at e are nested suffixes; the state at e is the one
+//     with the smallest s.  So follower s keeps its hits at e > M(s), the largest
+//     extent of the followers with a smaller start -- an exclusive prefix max in
+//     start order.  (If the follower with the smallest start alive at e is not on
+//     a final node, no later one is: a final suffix makes the longer node final,
+//     acsmx.c:417-429.)  Samples are taken in position order and the offsets of one
+//     sample in descending order, so followers come out in start order by
+//     construction; the prefix max runs inside the wave that owns the tile, and
+//     across tiles in the emit kernel.
 //
-// The state carried into the buffer (init_state) is handled by a walker at
-// position 0 that starts from it.  Work is capped -- table steps per walker,
-// walker rounds per 8192 positions, hits per 32768 positions; texts beyond the caps
-// (one endless deep run, a match at every byte) raise a device flag and the
-// chain pipeline, enqueued right behind and otherwise a row of early-exit
-// launches, produces the planes instead.
+// The state carried into the buffer (init_state) is a path that started before
+// byte 0: one lane walks the real DFA from it (cold plane + depth table) while its
+// start stays < 0; it precedes every follower in start order.  last_state: the
+// follower with the smallest start that is alive at the last byte, else the DFA
+// state after the last D-1 bytes from the root (depth < D there).
+//
+// Two launches:
+//   k_sieve       persistent workgroups; a wave owns a tile of the text: reads it
+//                 16 B per lane, probes, checks and follows what is flagged, keeps
+//                 the tile's hits in position order, writes a 32-byte tile summary
+//   k_sieve_emit  exclusive prefix max / prefix sum over the tile summaries, drops
+//                 the shadowed head of each list, copies the records to the planes
+// Work is capped (hits per tile, followers per sample, hits per follower); a text
+// beyond the caps sets a gate word and the chain pipeline, enqueued right behind
+// as early-exit launches, produces the planes instead.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <vector>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -58,408 +63,795 @@
 #include "acm_internal.h"
 #include "deep_walk.h"
 #include "device_dfa.h"
+#include "sieve_tables.h"
 #include "sparse.h"
 
 namespace {
 
-using acm_dev::ChainText;
-using acm_dev::Deep;
-using acm_dev::deep_step;
-using acm_dev::fast_forward;
+using acm_dev::agree16;
 
-constexpr int kFilterBlock = 1024;
-constexpr int kWalkBlock = 256;            // threads of a SW workgroup
-constexpr int kWalkWaves = kWalkBlock / 64;
-constexpr uint32_t kLaneWords = 2;         // words (of 64 text positions) per lane (1, 2, 4 measured: 2 is best) ...
-constexpr uint32_t kWaveWords = 64 * kLaneWords;             // ... per wave: 8192 positions
-constexpr uint32_t kBlockWords = kWalkWaves * kWaveWords;    // ... per workgroup: 32768 positions
-constexpr uint32_t kIterCap = 256;         // table steps one walker may take ...
-constexpr uint32_t kRunCap = 1024;         // ... or skip this many repeats of one byte in a self-looping state
-constexpr uint32_t kForwardCap = 4096;     // ... each followed by this many fast-forwarded bytes at most
-constexpr uint32_t kMaxWalkWave = 2048;    // walkers per wave (8192 positions): 32 rounds of 64
-constexpr uint32_t kMaxHits = 256;         // staged hits per workgroup (32768 positions)
+constexpr int kBlock = 1024;               // threads of a k_sieve workgroup
+constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kTilesPerChecker = 8;   // tiles whose flagged samples one wave of k_sieve_check takes
+constexpr int kCheckBlock = 64;            // threads of a k_sieve_check workgroup
+constexpr uint32_t kQ2Cap = 64 + 64 * 8;   // followers a checker queues: what a round leaves + 64 samples x 8 offsets
+constexpr uint32_t kMinTile = 1024;        // bytes; one 16-byte group per lane
+constexpr uint32_t kMaxTiles = 4096;       // the tile size doubles until the text has at most this many
+constexpr uint32_t kSummaryWords = 8;      // per tile: extent + 1, hits, first, last position, alive key, alive node
+constexpr uint32_t kGaveUp = 0xFFFFFFFFu;  // hit count of a tile whose list was full (cannot happen: geometry_for)
+constexpr uint32_t kMarkerFailed = 0xDEADu; // path marker of a scan that did not produce planes
+constexpr uint32_t kDenseDivisor = 128;    // more than a record per this many bytes: a dense batch
+constexpr int kEmitBlock = 1024;
+constexpr uint32_t kRowsPerThread = (kMaxTiles + 1 + kEmitBlock - 1) / kEmitBlock;
 
-struct SparseArgs {
-	const uint64_t *deep;     // [states][256] next | depth(next) << 32 | run(next) << 48
+struct SieveArgs {
+	// tables
+	const uint32_t *bloom;
+	uint32_t bloom_words, bloom_log_words;
+	const uint4 *gram;
+	uint32_t gram_log_buckets, gram_probes;
+	const uint4 *prefix;
+	uint32_t prefix_log_slots, prefix_probes;
+	const uint4 *rec, *edges;
+	uint32_t report_state;        // planes get the final state's reference id instead of its pattern
+	const uint8_t *in_byte;
+	const uint32_t *cold;
+	const uint16_t *depth;
 	const int32_t *out;
 	const uint32_t *dev2ref;
-	const uint8_t *in_byte;
-	const uint32_t *bloom;    // [bloom_words] blocked Bloom filter of the depth-3 trigrams
-	uint32_t bloom_words, bloom_log_words;
-	const uint32_t *t2g;      // [65536] state after bytes (p, c) from the root, index p | c << 8
+	uint32_t F, D;
+	// text
 	const uint4 *text16;
 	const uint8_t *text;
 	uint32_t n, n_pad;
-	uint32_t F;
-	uint32_t init_state;
-	uint32_t drop_before;
+	uint32_t init_state, drop_before;
 	int32_t off_shift;
-	uint32_t nwords, nblocks;
+	// geometry
+	uint32_t tile_bytes, ntiles, cap;
 	// workspace
-	uint16_t *mask;                // [n_pad / 16 + 8] candidate bits
-	uint32_t *block_extent;        // [nblocks] largest deep extent + 1 of the workgroup's walkers
-	uint32_t *block_hits;          // [nblocks] hits the workgroup staged
-	uint2 *hit_list;               // [nblocks][kMaxHits] {position, pattern}, ascending positions
-	uint32_t *flags;               // [0] gave up -> chain pipeline runs
-	uint32_t *path_marker;         // acm_scan_path_taken: set to SPARSE here, overwritten by the chain kernels
-	uint32_t *giveups;             // host-visible count of batches given up on (adaptive AUTO mode), or null
-	unsigned long long *keeper;    // start position << 32 | state of the first walker that reached the end
+	uint2 *samples;      // [ntiles][scap] {position, 3-gram} of the samples the filter flagged, ascending
+	uint32_t *scount;    // [ntiles] how many (kGaveUp: more than scap)
+	uint32_t scap;
+	uint32_t *summary;   // [ntiles + 1][kSummaryWords]; row 0: the carried-state walker
+	uint2 *lists;        // [ntiles + 1][cap] {position, plane value}, ascending
+	uint32_t *misc;      // [0] state after the last D-1 bytes from the root
+	uint32_t *path_marker, *giveups;
+	uint32_t nt;                  // experiment: non-temporal text loads
+	unsigned long long *stamps;   // debugging aid (ACM_SIEVE_STAMPS): [wave][8] clock readings, or null
 	// output
 	int32_t *pat_plane, *off_plane;
 	uint32_t plane_capacity;
 };
 
-// ------------------------------------------------------------------ SF ---
-
-// bit 0 of the result: both filter bits of the trigram (low 24 bits of tri) are set
-__device__ __forceinline__ uint32_t bloom_test(const uint32_t *bloom, uint32_t tri, uint32_t word_shift)
-{
-	const uint32_t p1 = __umul24(tri, acm::kBloomMul1), p2 = __umul24(tri, acm::kBloomMul2);
-	const uint32_t w = bloom[p1 >> word_shift];
-	return (w >> (p2 >> 27)) & (w >> ((p2 >> 22) & 31));
-}
-
-// shifts the candidate bit of position K of the 16-byte group into m from the top
-template <int K>
-__device__ __forceinline__ uint32_t probe(const uint32_t *bloom, uint32_t word_shift, const uint32_t (&x)[5],
-    uint32_t m)
-{
-	// bytes (K-2, K-1, K) of the group; x[0] is the dword in front of it
-	constexpr int lo = (K + 2) / 4, sh = (K + 2) % 4;
-	const uint32_t v = sh == 0 ? x[lo] : __builtin_amdgcn_alignbyte(x[lo + 1 > 4 ? 4 : lo + 1], x[lo], sh);
-	return __builtin_amdgcn_alignbit(bloom_test(bloom, v, word_shift), m, 1);
-}
-
-// persistent workgroups keep the filter in LDS; a wave-iteration reads 1 KiB of
-// text with one coalesced 16 B/lane load, issued one iteration ahead of its use
-__global__ __launch_bounds__(kFilterBlock) void k_sparse_filter(SparseArgs a)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
-	{
-		const uint4 *src = (const uint4 *)a.bloom;
-		uint4 *dst = (uint4 *)bloom;
-		const uint32_t n16 = a.bloom_words / 4;
-		const uint32_t rot = (blockIdx.x * 1021u) % n16;
-		for (uint32_t i = threadIdx.x; i < n16; i += kFilterBlock) {
-			uint32_t j = i + rot;
-			j = j >= n16 ? j - n16 : j;
-			dst[j] = src[j];
-		}
-	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {   // first kernel of the pipeline: reset what the others accumulate into
-		a.flags[0] = 0;
-		*a.keeper = ~0ull;
-		*a.path_marker = (uint32_t)ACM_SCAN_MODE_SPARSE;
-	}
-	__syncthreads();
-	const uint32_t word_shift = 32 - a.bloom_log_words;
-	const uint32_t n16 = a.n_pad >> 4;
-	const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * (kFilterBlock / 64) + (threadIdx.x >> 6);
-	const uint32_t nw = gridDim.x * (kFilterBlock / 64);
-	const uint32_t *text32 = (const uint32_t *)a.text16;
-	const uint32_t tiles = (n16 + 8 + 63) / 64;   // wave-iterations, including the 8 padding cells
-	uint4 w = make_uint4(0, 0, 0, 0);
-	uint32_t prev = 0;
-	if (wave < tiles && wave * 64 + lane < n16) {
-		w = a.text16[wave * 64 + lane];
-		prev = wave * 64 + lane ? text32[(wave * 64 + lane) * 4 - 1] : 0u;
-	}
-	for (uint32_t t = wave; t < tiles; t += nw) {
-		const uint32_t i16 = t * 64 + lane;
-		const uint32_t x[5] = { prev, w.x, w.y, w.z, w.w };
-		const uint32_t i16n = (t + nw) * 64 + lane;   // next iteration's group: load now, use then
-		if (t + nw < tiles && i16n < n16) {
-			w = a.text16[i16n];
-			prev = text32[i16n * 4 - 1];
-		}
-		if (i16 >= n16) {
-			if (i16 < n16 + 8)
-				a.mask[i16] = 0;   // padding the walkers may read
-			continue;
-		}
-		uint32_t m = 0;
-		m = probe<0>(bloom, word_shift, x, m); m = probe<1>(bloom, word_shift, x, m);
-		m = probe<2>(bloom, word_shift, x, m); m = probe<3>(bloom, word_shift, x, m);
-		m = probe<4>(bloom, word_shift, x, m); m = probe<5>(bloom, word_shift, x, m);
-		m = probe<6>(bloom, word_shift, x, m); m = probe<7>(bloom, word_shift, x, m);
-		m = probe<8>(bloom, word_shift, x, m); m = probe<9>(bloom, word_shift, x, m);
-		m = probe<10>(bloom, word_shift, x, m); m = probe<11>(bloom, word_shift, x, m);
-		m = probe<12>(bloom, word_shift, x, m); m = probe<13>(bloom, word_shift, x, m);
-		m = probe<14>(bloom, word_shift, x, m); m = probe<15>(bloom, word_shift, x, m);
-		m >>= 16;
-		if (i16 == 0)
-			m &= ~3u;                        // no full trigram yet: the position-0 walker covers these
-		const uint32_t pos0 = i16 << 4;
-		if (pos0 + 16 > a.n)                 // bytes past the end of the text
-			m &= (1u << (a.n - pos0)) - 1u;
-		a.mask[i16] = (uint16_t)m;
-	}
-}
-
-// ------------------------------------------------------------------ SE ---
-
-// hits of one workgroup, in LDS until they are written to the planes
-struct HitList {
-	uint32_t pos[kMaxHits];
-	uint32_t state[kMaxHits];
-	uint32_t owner[kMaxHits];   // wave << 16 | round << 8 | lane of the walker; bit 31: dropped
-	int32_t covered[kMaxHits];  // largest deep extent of the wave's walkers in front of that walker
-	uint32_t count;             // may run past kMaxHits: then the workgroup gave up
+struct __attribute__((packed)) Unaligned8 {
+	uint64_t v;
 };
 
-// One walker: from the state before position p0 over p0, p0 + 1, ... while the
-// state is deep or the next position is a candidate.  end_out: the last deep
-// position (-1: none).  Returns false when a cap was hit.
-__device__ __forceinline__ bool walker(const SparseArgs &a, HitList &hits, const uint64_t *lmask, uint32_t word0,
-    uint32_t owner, uint32_t p0, int32_t &end_out)
+// 8 text bytes at any position; bytes past the padded end read as zero
+__device__ __forceinline__ uint64_t load8(const SieveArgs &a, uint32_t pos)
 {
-	uint32_t state, min_steps = 0;
-	if (p0 == 0) {
-		state = a.init_state;
-		min_steps = 2;   // positions 0 and 1 have no candidate bit of their own
-	} else {
-		state = a.t2g[(uint32_t)a.text[p0 - 2] | ((uint32_t)a.text[p0 - 1] << 8)];
-	}
-	int32_t end = -1;
-	uint32_t p = p0, iters = 0;
-	const uint32_t tbase = p0 & ~15u;
-	ChainText txt(a, tbase);
-	bool reached_end = false, ok = true;
-	for (;;) {
-		if (p >= a.n) {
-			reached_end = true;
-			break;
-		}
-		const uint32_t byte = txt.at(p - tbase + 1);
-		Deep d = deep_step(a, state, byte);
-		if (d.s == state && d.depth >= 3 && state < a.F) {
-			// A deep, non-final state that maps to itself: the text repeats one byte (a zero page
-			// under a signature that starts with zeros) and nothing changes until it stops doing
-			// so.  Skip the repeats 16 per load level; past kRunCap bytes the run is the chain
-			// pipeline's job (it does not care how long a run is).
-			const uint64_t splat = 0x0101010101010101ull * byte;
-			uint32_t skipped = 0;
-			while (p + 17 <= a.n && skipped < kRunCap) {
-				const acm_dev::Unaligned16 *t = (const acm_dev::Unaligned16 *)(a.text + p + 1);
-				const uint64_t x0 = t->lo ^ splat, x1 = t->hi ^ splat;
-				const uint32_t same = x0 ? (uint32_t)(__ffsll((long long)x0) - 1) >> 3
-							 : 8u + (x1 ? (uint32_t)(__ffsll((long long)x1) - 1) >> 3 : 8u);
-				p += same;
-				skipped += same;
-				if (same < 16)
-					break;
-			}
-			if (skipped >= kRunCap) {
-				ok = false;
-				break;
-			}
-		}
-		state = d.s;
-		const bool deep = d.depth >= 3;
-		if (deep)
-			end = (int32_t)p;
-		if (state >= a.F && p >= a.drop_before) {
-			const uint32_t slot = atomicAdd(&hits.count, 1u);
-			if (slot >= kMaxHits) {
-				ok = false;
-				break;
-			}
-			hits.pos[slot] = p;
-			hits.state[slot] = state;
-			hits.owner[slot] = owner;
-		}
-		if (deep && d.run != 0 && state < a.F) {
-			// k more deep, non-final positions along a unary trie path, 16 per load level
-			const uint32_t k = fast_forward(a, d, p + 1, min(a.n - p - 1, kForwardCap));
-			p += k;
-			state = d.s;
-			end = (int32_t)p;
-		}
-		p++;
-		if (!deep && p - p0 >= min_steps) {
-			if (p >= a.n) {
-				reached_end = true;
-				break;
-			}
-			// candidate bit of position p: in LDS for the wave's own positions
-			const uint32_t wi = (p >> 6) - word0;
-			const uint64_t mbits = wi < kWaveWords ? lmask[wi] : *(const uint64_t *)(a.mask + (size_t)(p >> 6) * 4);
-			if (!((mbits >> (p & 63)) & 1ull))
-				break;
-		}
-		if (++iters >= kIterCap) {
-			ok = false;
-			break;
-		}
-	}
-	end_out = end;
-	if (reached_end)   // the earliest such walker is exact at the last byte: it carries last_state
-		atomicMin(a.keeper, ((unsigned long long)p0 << 32) | state);
-	return ok;
+	if (pos + 8 <= a.n_pad)
+		return ((const Unaligned8 *)(a.text + pos))->v;
+	if (pos >= a.n_pad)
+		return 0;
+	return *(const uint64_t *)(a.text + a.n_pad - 8) >> (8 * (pos - (a.n_pad - 8)));
 }
 
-__global__ __launch_bounds__(kWalkBlock, 8) void k_sparse_walk(SparseArgs a)
+// bytes sh .. sh+7 of the 16-byte string lo:hi
+__device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh)
 {
-	__shared__ HitList hits;
-	__shared__ uint64_t lmask[kWalkWaves][kWaveWords];       // candidate bits of the wave's words
-	__shared__ int32_t wave_max[kWalkWaves];
-	__shared__ uint32_t s_gave_up, s_survivors;
-	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	static_assert(kMaxHits == kWalkBlock, "one thread clears one slot");
-	hits.owner[threadIdx.x] = 0xFFFFFFFFu;   // a reserved but not yet written slot belongs to nobody
-	if (threadIdx.x == 0) {
-		hits.count = 0;
-		s_gave_up = 0;
-		s_survivors = 0;
-	}
-	__syncthreads();
-	// a lane owns kLaneWords consecutive words, a wave kWaveWords
-	const uint32_t word0 = (blockIdx.x * kWalkWaves + wv) * kWaveWords;   // the wave's first word
-	const uint32_t w = word0 + lane * kLaneWords;                          // the lane's first word
+	const uint32_t bits = sh * 8;
+	return bits == 0 ? lo : bits >= 64 ? hi : (lo >> bits) | (hi << (64 - bits));
+}
 
-	// the walkers of the wave, in position order
-	uint64_t starts[kLaneWords];
-	uint32_t cnt = 0;
-	{
-		uint64_t prev = (w && w < a.nwords) ? (uint64_t)(a.mask[(size_t)w * 4 - 1] >> 15) : 0ull;
-#pragma unroll
-		for (uint32_t j = 0; j < kLaneWords; j++) {
-			const uint64_t m = w + j < a.nwords ? *(const uint64_t *)(a.mask + (size_t)(w + j) * 4) : 0ull;
-			starts[j] = m & ~((m << 1) | prev);   // first bit of every run of candidate bits
-			prev = m >> 63;
-			lmask[wv][lane * kLaneWords + j] = m;
-		}
-		if (w == 0)
-			starts[0] |= 1ull;   // the walker that carries init_state (bits 0, 1 are never candidates)
-#pragma unroll
-		for (uint32_t j = 0; j < kLaneWords; j++)
-			cnt += (uint32_t)__popcll(starts[j]);
-	}
-	uint32_t inc = cnt;
+__device__ __forceinline__ uint32_t bloom_hit(const uint32_t *bloom, uint32_t gram, uint32_t word_shift)
+{
+	const uint32_t w = bloom[acm::mul24(gram, acm::kSieveMulA) >> word_shift];
+	const uint32_t p = acm::mul24(gram, acm::kSieveMulB);
+	return (w >> (p >> 27)) & (w >> ((p >> 22) & 31)) & 1u;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
+{
+	uint32_t incl = v;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = __shfl_up(inc, o, 64);
+		const uint32_t t = __shfl_up(incl, o, 64);
 		if (lane >= (uint32_t)o)
-			inc += t;
+			incl += t;
 	}
-	const uint32_t total = __shfl(inc, 63, 64), base = inc - cnt;
-	bool ok = total <= kMaxWalkWave;   // wave-uniform
-	int32_t carry = -1;                // largest deep extent of the wave's walkers so far
-	uint32_t settled = 0;              // hits below this index have their 'covered' value
-	const uint32_t rounds = ok ? (total + 63) / 64 : 0;
-	for (uint32_t r = 0; r < rounds; r++) {   // walker k runs on lane k % 64, whichever word it starts in
-		if (__any(*(volatile uint32_t *)a.flags != 0))
-			break;   // some walker of the batch hit a cap: the chain pipeline will redo it all
-		const uint32_t k = r * 64 + lane;
-		const bool valid = k < total;
-		uint32_t owner_lane = 0;               // the last lane whose first walker index is <= k
-#pragma unroll
-		for (int step = 32; step > 0; step >>= 1) {
-			const uint32_t cand = owner_lane + step;
-			const uint32_t b = __shfl(base, cand & 63, 64);
-			if (cand < 64 && b <= k)
-				owner_lane = cand;
-		}
-		uint32_t skip = k - __shfl(base, owner_lane, 64);   // walkers of the owner lane in front of k
-		uint64_t word_starts = 0;                            // start bits of the word walker k is in
-		uint32_t word_index = 0;
-		bool found = false;
-#pragma unroll
-		for (uint32_t j = 0; j < kLaneWords; j++) {
-			const uint32_t lo = __shfl((uint32_t)starts[j], owner_lane, 64);
-			const uint32_t hi = __shfl((uint32_t)(starts[j] >> 32), owner_lane, 64);
-			const uint64_t sj = ((uint64_t)hi << 32) | lo;
-			const uint32_t c = (uint32_t)__popcll(sj);
-			if (!found) {
-				if (skip < c) {
-					word_starts = sj;
-					word_index = j;
-					found = true;
-				} else {
-					skip -= c;
-				}
-			}
-		}
-		int32_t end = -1;
-		if (valid) {
-			for (uint32_t i = 0; i < skip; i++)
-				word_starts &= word_starts - 1;
-			const uint32_t p0 = ((word0 + owner_lane * kLaneWords + word_index) << 6) +
-					    (uint32_t)__ffsll((long long)word_starts) - 1;
-			ok &= walker(a, hits, lmask[wv], word0, (wv << 16) | (r << 8) | lane, p0, end);
-			if (!ok)
-				a.flags[0] = 1;   // at once: every wave of the batch stops at its next round
-		}
-		int32_t incm = end;   // inclusive prefix max over the round, then exclusive + earlier rounds
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const int32_t t = __shfl_up(incm, o, 64);
-			if (lane >= (uint32_t)o)
-				incm = max(incm, t);
-		}
-		int32_t excl = __shfl_up(incm, 1, 64);
-		if (lane == 0)
-			excl = -1;
-		// the hits this round's walkers staged learn what the walkers in front of theirs cover
-		// (the value sits in the owner's lane: a shuffle, in a loop every lane runs)
-		const int32_t before = max(carry, excl);
-		const uint32_t staged = min(*(volatile uint32_t *)&hits.count, kMaxHits);
-		for (uint32_t i = settled; i < staged; i++) {
-			const uint32_t o = *(volatile uint32_t *)&hits.owner[i];
-			const int32_t v = __shfl(before, o & 63u, 64);
-			if (lane == 0 && (o >> 8) == ((wv << 8) | r))
-				hits.covered[i] = v;
-		}
-		settled = staged;
-		carry = max(carry, __shfl(incm, 63, 64));
-	}
-	if (!ok)
-		s_gave_up = 1;
-	if (lane == 0)
-		wave_max[wv] = carry;
-	__syncthreads();
+	total = __shfl(incl, 63, 64);
+	return incl - v;
+}
 
-	// drop the hits an earlier walker of this workgroup covers
-	const uint32_t nh = min(hits.count, kMaxHits);
-	for (uint32_t i = threadIdx.x; i < nh; i += kWalkBlock) {
-		const uint32_t o = hits.owner[i], ow = o >> 16;
-		int32_t m = hits.covered[i];
-		for (uint32_t v = 0; v < ow; v++)
-			m = max(m, wave_max[v]);
-		if ((int32_t)hits.pos[i] <= m)
-			hits.owner[i] = o | 0x80000000u;
-	}
-	__syncthreads();
-	// the others have distinct positions: rank = number of survivors in front
-	uint32_t survivors = 0;
-	for (uint32_t i = threadIdx.x; i < nh; i += kWalkBlock) {
-		if (hits.owner[i] & 0x80000000u)
-			continue;
-		const uint32_t pos = hits.pos[i];
-		uint32_t rank = 0;
-		for (uint32_t j = 0; j < nh; j++)
-			rank += (!(hits.owner[j] & 0x80000000u) && hits.pos[j] < pos) ? 1u : 0u;
-		a.hit_list[(size_t)blockIdx.x * kMaxHits + rank] = make_uint2(pos, (uint32_t)a.out[hits.state[i]]);
-		survivors++;
-	}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, uint32_t lane)
+{
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		survivors += __shfl_xor(survivors, o, 64);
-	if (lane == 0 && survivors)
-		atomicAdd(&s_survivors, survivors);
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int32_t bm = -1;
-		for (int i = 0; i < kWalkWaves; i++)
-			bm = max(bm, wave_max[i]);
-		a.block_extent[blockIdx.x] = (uint32_t)(bm + 1);
-		a.block_hits[blockIdx.x] = s_survivors;
-		if (s_gave_up)
-			a.flags[0] = 1;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o, 64);
+		if (lane >= (uint32_t)o)
+			v = max(v, t);
+	}
+	return v;
+}
+
+// Hits of one lane in one round, newest first: a hit is pushed in front, the others move
+// one slot back (no slot is picked by a run-time index: such a struct ends up in scratch).
+struct LaneHits {
+	uint32_t n;          // hits noted; more than 4: the round gives up
+	uint32_t e0, v0, e1, v1, e2, v2, e3, v3;   // position, plane value
+	uint32_t levels;     // debugging aid: dependent load levels of the lane's follower
+};
+
+__device__ __forceinline__ void note_hit(LaneHits &h, uint32_t x, uint32_t value, bool take)
+{
+	h.e3 = take ? h.e2 : h.e3;
+	h.v3 = take ? h.v2 : h.v3;
+	h.e2 = take ? h.e1 : h.e2;
+	h.v2 = take ? h.v1 : h.v2;
+	h.e1 = take ? h.e0 : h.e1;
+	h.v1 = take ? h.v0 : h.v1;
+	h.e0 = take ? x : h.e0;
+	h.v0 = take ? value : h.v0;
+	h.n += take ? 1u : 0u;
+}
+
+// bytes the 64-byte windows at p and q agree on before the first difference (64: all).  All
+// eight loads are unconditional and in flight together: one latency for up to 64 bytes (a load
+// inside a branch gets its own wait: four round trips instead of one).
+__device__ __forceinline__ uint32_t agree64(const uint8_t *p, const uint8_t *q)
+{
+	uint64_t lo[4], hi[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		acm_dev::diff_bytes16(p + k * 16, q + k * 16, lo[k], hi[k]);
+	uint32_t same = 64;
+#pragma unroll
+	for (int k = 3; k >= 0; k--) {   // the earliest difference is written last
+		same = hi[k] ? (uint32_t)k * 16 + 8 + (((uint32_t)__ffsll((long long)hi[k]) - 1u) >> 3) : same;
+		same = lo[k] ? (uint32_t)k * 16 + (((uint32_t)__ffsll((long long)lo[k]) - 1u) >> 3) : same;
+	}
+	return same;
+}
+
+// One follower: from 'node' (depth D, last matched byte at x) along its trie path.
+// Returns extent + 1; at_end: the path was still alive at the last byte (on 'node').
+// What happens to the final nodes it enters depends on 'mode':
+//   kKeep   the first pass of a round: up to four go to registers (h), all are counted (h.n)
+//   kCount  a follower with more than four: count those at positions >= floor (h.n), note
+//           the first and the last of them (h.e3, h.e0)
+//   kWrite  ... and write those to dst, ascending
+enum { kKeep = 0, kCount = 1, kWrite = 2 };
+struct Follow {
+	uint32_t extent1, node;
+	bool at_end;
+};
+
+__device__ __forceinline__ void final_node(LaneHits &h, uint32_t x, uint32_t value, bool take, int mode, uint32_t floor,
+    uint2 *dst)
+{
+	if (mode == kKeep) {
+		note_hit(h, x, value, take);
+	} else if (take && x >= floor) {
+		if (mode == kWrite)
+			dst[h.n] = make_uint2(x, value);
+		if (h.n == 0)
+			h.e3 = x;
+		h.e0 = x;
+		h.n++;
 	}
 }
 
-constexpr int kEmitBlock = 1024;
+__device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32_t node, uint32_t run, uint32_t x, int mode,
+    uint32_t floor, uint2 *dst)
+{
+	Follow f;
+	if (node >= a.F)   // a pattern of exactly D bytes, or one that ends a longer suffix
+		final_node(h, x, (uint32_t)a.out[node], x >= a.drop_before, mode, floor, dst);
+	for (;;) {
+		if (x + 1 >= a.n)
+			break;
+		h.levels++;
+		if (run) {   // unary, non-final path ahead: node+1, node+2, ... as long as the text agrees
+			const uint32_t want = min(min(run, 64u), a.n - 1 - x);
+			uint32_t same;
+			if (x + 65 <= a.n_pad) {
+				same = agree64(a.in_byte + node + 1, a.text + x + 1);
+			} else {
+				same = 0;
+				while (same < want && a.in_byte[node + 1 + same] == a.text[x + 1 + same])
+					same++;
+			}
+			const uint32_t k = min(same, want);
+			node += k;
+			x += k;
+			run -= k;
+			if (k < want)
+				break;
+			continue;
+		}
+		uint32_t c = a.text[x + 1];   // both loads before anything looks at either
+		const uint4 rec = a.rec[node];
+		__asm__ volatile("" : "+v"(c));   // (keeps the byte's load from sinking into the branch that uses it)
+		const uint32_t nchild = rec.y & 0x1FFu;
+		uint32_t value;
+		bool leaf;
+		if (nchild == 0)
+			break;
+		if (nchild == 1) {
+			if ((rec.x >> 24) != c)
+				break;
+			node = rec.x & 0xFFFFFFu;
+			run = rec.y >> 16;
+			leaf = (rec.y >> 9) & 1u;
+			value = a.report_state ? rec.w : rec.z;
+		} else {
+			const uint4 *e = a.edges + (rec.x & 0xFFFFFFu);
+			bool hit = false;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			for (uint32_t i = 0; i < nchild && !hit; i++) {   // sorted by byte
+				v = e[i];
+				const uint32_t b = v.x & 0xFFu;
+				if (b == c)
+					hit = true;
+				else if (b > c)
+					break;
+			}
+			if (!hit)
+				break;
+			node = v.x >> 8;
+			run = v.y & 0xFFFFu;
+			leaf = (v.y >> 16) & 1u;
+			value = a.report_state ? v.w : v.z;
+		}
+		x++;
+		final_node(h, x, value, node >= a.F && x >= a.drop_before, mode, floor, dst);
+		if (leaf)
+			break;
+	}
+	f.at_end = x + 1 >= a.n;   // however the loop ended: the path reached the last byte
+	f.extent1 = x + 1;
+	f.node = node;
+	return f;
+}
+
+// State of a tile while its samples are checked; one per wave of the workgroup, in LDS.
+struct Tile {
+	uint32_t carry;      // largest extent + 1 of the followers checked so far, this tile's or in front of it
+	uint32_t count;      // hits staged
+	uint32_t first, last;
+	uint32_t akey, anode;
+	uint32_t gave_up;
+	uint32_t pad;
+};
+
+__device__ __forceinline__ void write_summary(const SieveArgs &a, const Tile &t, uint32_t row)
+{
+	uint32_t *s = a.summary + (size_t)row * kSummaryWords;
+	*(uint4 *)s = make_uint4(t.carry, t.gave_up ? kGaveUp : t.count, t.first, t.last);
+	*(uint2 *)(s + 4) = make_uint2(t.akey, t.anode);
+}
+
+// What a checker wave keeps in LDS between its two stages: the followers stage 1 found,
+// in start order, until stage 2 has a full round of them.
+struct FollowerQueue {
+	uint32_t *start, *node_slot, *run;   // [kQ2Cap] each; node | tile slot << 24
+	uint32_t count;
+};
+
+// Stage 1, one flagged sample per lane (ascending positions): exact gram lookup, then the
+// prefix lookups of all the offsets the gram occurs at -- every load of a step in flight
+// together: two dependent steps whatever the number of offsets.  What is a trie path goes
+// to the follower queue, the lanes' followers one behind the other, a lane's own in
+// descending offset = ascending start order.
+template <int W>
+__device__ __forceinline__ void stage1_round(const SieveArgs &a, FollowerQueue &fq, uint32_t p, uint32_t gram,
+    uint32_t slot, bool act, uint32_t lane)
+{
+	// the 24 bytes around the sample: A = [p-8, p), B = [p, p+8), C = [p+8, p+16)
+	uint64_t A = 0, B = 0, C = 0;
+	uint32_t mask = 0;
+	if (act) {
+		// four loads and nothing between them: the window at clamped addresses (the first and the last
+		// bytes of the text are put right afterwards) and the gram's bucket
+		const uint32_t last8 = a.n_pad - 8;
+		const uint32_t pb = min(p, last8), pc = min(p + 8, last8);
+		const uint64_t va = ((const Unaligned8 *)(a.text + (p >= 8 ? p - 8 : 0)))->v;
+		const uint64_t vb = ((const Unaligned8 *)(a.text + pb))->v;
+		const uint64_t vc = ((const Unaligned8 *)(a.text + pc))->v;
+		A = p >= 8 ? va : p ? va << (8 * (8 - p)) : 0ull;
+		B = p <= last8 ? vb : p >= a.n_pad ? 0ull : vb >> (8 * (p - last8));
+		C = p + 8 <= last8 ? vc : p + 8 >= a.n_pad ? 0ull : vc >> (8 * (p + 8 - last8));
+		const uint32_t bmask = (1u << a.gram_log_buckets) - 1u;
+		uint32_t b = acm::sieve_gram_bucket(gram, a.gram_log_buckets);
+		for (uint32_t probe = 0; probe < a.gram_probes; probe++, b = (b + 1) & bmask) {
+			const uint4 e = a.gram[b];
+			if (e.x && (e.x & 0xFFFFFFu) == gram) mask = e.x >> 24;
+			else if (e.y && (e.y & 0xFFFFFFu) == gram) mask = e.y >> 24;
+			else if (e.z && (e.z & 0xFFFFFFu) == gram) mask = e.z >> 24;
+			else if (e.w && (e.w & 0xFFFFFFu) == gram) mask = e.w >> 24;
+			if (mask || !e.x || !e.y || !e.z || !e.w)
+				break;   // found, or a bucket with room: the gram is not in the table
+		}
+	}
+	if (!__ballot(mask != 0))
+		return;
+	// bytes of the key beyond D are zero in the table
+	const uint64_t klo = a.D >= 8 ? ~0ull : (1ull << (8 * a.D)) - 1ull;
+	const uint32_t khi = a.D >= 10 ? 0xFFFFu : a.D <= 8 ? 0u : 0xFFu;
+	const uint32_t smask = (1u << a.prefix_log_slots) - 1u;
+	// (keys are recomputed where they are needed instead of kept: registers)
+	auto key_of = [&](uint32_t o, uint32_t &k0, uint32_t &k1, uint32_t &k2) {
+		const uint64_t lo = funnel(A, B, 8 - o) & klo;
+		k2 = (uint32_t)funnel(B, C, 8 - o) & khi;
+		k0 = (uint32_t)lo;
+		k1 = (uint32_t)(lo >> 32);
+	};
+	uint4 ent[W];
+#pragma unroll
+	for (int o = W - 1; o >= 0; o--) {
+		ent[o] = make_uint4(0, 0, 0, 0);
+		// a start before byte 0 is the carried-state walker's path; one too close to the end cannot be final
+		if (((mask >> o) & 1u) && (uint32_t)o <= p && p - (uint32_t)o + a.D <= a.n) {
+			uint32_t k0, k1, k2;
+			key_of((uint32_t)o, k0, k1, k2);
+			ent[o] = a.prefix[acm::sieve_prefix_slot(k0, k1, k2, a.prefix_log_slots)];
+		}
+	}
+	uint32_t vmask = 0;
+#pragma unroll
+	for (int o = W - 1; o >= 0; o--) {
+		if (!ent[o].w)
+			continue;
+		uint32_t k0, k1, k2;
+		key_of((uint32_t)o, k0, k1, k2);
+		uint32_t at = acm::sieve_prefix_slot(k0, k1, k2, a.prefix_log_slots);
+		for (uint32_t probe = 1;; probe++) {
+			if (ent[o].x == k0 && ent[o].y == k1 && (ent[o].z & 0xFFFFu) == k2) {
+				vmask |= 1u << o;
+				break;
+			}
+			if (probe >= a.prefix_probes)
+				break;
+			at = (at + 1) & smask;   // another key's slot: the next one (an eighth of them are taken)
+			ent[o] = a.prefix[at];
+			if (!ent[o].w)
+				break;
+		}
+	}
+	uint32_t total;
+	uint32_t idx = fq.count + wave_excl_sum((uint32_t)__popc(vmask), lane, total);
+	if (!total)
+		return;
+#pragma unroll
+	for (int o = W - 1; o >= 0; o--)
+		if ((vmask >> o) & 1u) {
+			fq.start[idx] = p - (uint32_t)o;
+			fq.node_slot[idx] = ent[o].w | (slot << 24);
+			fq.run[idx] = ent[o].z >> 16;
+			idx++;
+		}
+	fq.count += total;
+	__builtin_amdgcn_wave_barrier();
+}
+
+// Stage 2, one follower per lane (ascending starts; equal tile slots are neighbours): follow,
+// shadow across the lanes, append the surviving hits to their tiles' lists.
+__device__ __forceinline__ void stage2_round(const SieveArgs &a, Tile *tiles, uint32_t row0, uint32_t s, uint32_t node,
+    uint32_t run, uint32_t slot, bool act, uint32_t lane, uint32_t &dbg_levels)
+{
+	LaneHits h;
+	uint32_t E = 0, akey = 0, anode = 0, M = 0, mine = 0, keep = 0, base = 0;
+	bool big = false;
+	uint2 *dst = nullptr;
+	// A lane whose follower enters more than four final nodes (nested patterns) goes through the
+	// loop three times: keep/count all, count what the shadow leaves, write that.  The others once.
+#pragma nounroll
+	for (int mode = kKeep; mode <= kWrite; mode++) {
+		if (mode == kKeep || big) {
+			h.n = 0;
+			h.e0 = h.v0 = h.e1 = h.v1 = h.e2 = h.v2 = h.e3 = h.v3 = 0;
+			h.levels = 0;
+		}
+		if (act && (mode == kKeep || big)) {
+			const Follow f = follow(a, h, node, run, s + a.D - 1, mode, M, dst);
+			E = f.extent1;
+			if (f.at_end) {
+				akey = s + 2;
+				anode = f.node;
+			}
+		}
+		if (mode == kKeep) {
+			if (a.stamps) {
+				uint32_t lv = h.levels;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1)
+					lv = max(lv, __shfl_xor(lv, o, 64));
+				dbg_levels += lv;
+			}
+			// shadow: a follower keeps its hits behind the extents of the followers in front of it -- of
+			// its own tile in earlier rounds (the tile's carry) and of this round (all tiles)
+			const uint32_t incl = wave_incl_max(E, lane);
+			uint32_t excl = __shfl_up(incl, 1, 64);
+			if (lane == 0)
+				excl = 0;
+			M = max(act ? tiles[slot].carry : 0u, excl);
+			big = h.n > 4;
+			if (!__ballot(big))
+				break;
+		} else if (mode == kCount) {
+			mine = big ? h.n : 0u;   // the write pass needs every lane's place in its tile's list: below
+			break;
+		}
+	}
+	// (the loop above ends after kKeep when no lane is big, after kCount otherwise; the write pass of the
+	// big lanes follows once the places are known)
+	if (!big) {
+		const uint32_t nh = min(h.n, 4u);   // slot 3 holds the oldest (smallest position) of four
+		if (nh > 3 && h.e3 >= M) keep |= 1u;
+		if (nh > 2 && h.e2 >= M) keep |= 2u;
+		if (nh > 1 && h.e1 >= M) keep |= 4u;
+		if (nh > 0 && h.e0 >= M) keep |= 8u;
+		mine = (uint32_t)__popc(keep);
+	}
+	uint32_t total;
+	base = wave_excl_sum(mine, lane, total);
+	const uint32_t he[4] = { h.e3, h.e2, h.e1, h.e0 }, hv[4] = { h.v3, h.v2, h.v1, h.v0 };
+	uint32_t firstpos, lastpos;
+	if (big) {   // kCount left the first and the last position in e3 and e0
+		firstpos = h.e3;
+		lastpos = h.e0;
+	} else {
+		firstpos = (keep & 1u) ? he[0] : (keep & 2u) ? he[1] : (keep & 4u) ? he[2] : he[3];
+		lastpos = (keep & 8u) ? he[3] : (keep & 4u) ? he[2] : (keep & 2u) ? he[1] : he[0];
+	}
+	const uint32_t incl = wave_incl_max(E, lane);
+	// one tile (a run of lanes with the same slot) at a time
+	unsigned long long rem = __ballot(act);
+	while (rem) {
+		const uint32_t fl = (uint32_t)__ffsll((long long)rem) - 1u;
+		const uint32_t scur = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)fl);
+		const bool mineseg = act && slot == scur;
+		const unsigned long long seg = __ballot(mineseg);
+		rem &= ~seg;
+		const uint32_t ll = 63u - (uint32_t)__clzll((long long)seg);
+		const uint32_t seg_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)fl);
+		const uint32_t seg_total = (uint32_t)__builtin_amdgcn_readlane((int)(base + mine), (int)ll) - seg_base;
+		const uint32_t segE = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)ll);
+		Tile *t = tiles + scur;
+		const uint32_t cnt0 = t->count;
+		const bool room = cnt0 + seg_total <= a.cap;   // (always: a list holds a hit per position the tile can reach)
+		if (mineseg && mine && room) {
+			uint2 *to = a.lists + (size_t)(row0 + scur) * a.cap + cnt0 + (base - seg_base);
+			if (big) {
+				dst = to;   // written by the third pass below
+			} else {
+				uint32_t k = 0;
+#pragma unroll
+				for (uint32_t i = 0; i < 4; i++)
+					if (keep & (1u << i))
+						to[k++] = make_uint2(he[i], hv[i]);
+			}
+		}
+		const unsigned long long keepers = __ballot(mineseg && mine != 0);
+		const unsigned long long alive = __ballot(mineseg && akey != 0);
+		uint32_t fp = 0, lp = 0, ak = 0, an = 0;
+		if (keepers) {
+			fp = (uint32_t)__builtin_amdgcn_readlane((int)firstpos, (int)((uint32_t)__ffsll((long long)keepers) - 1u));
+			lp = (uint32_t)__builtin_amdgcn_readlane((int)lastpos, (int)(63u - (uint32_t)__clzll((long long)keepers)));
+		}
+		if (alive) {
+			const int al = (int)((uint32_t)__ffsll((long long)alive) - 1u);
+			ak = (uint32_t)__builtin_amdgcn_readlane((int)akey, al);
+			an = (uint32_t)__builtin_amdgcn_readlane((int)anode, al);
+		}
+		if (lane == fl) {
+			t->carry = max(t->carry, segE);
+			if (!room)
+				t->gave_up = 1;
+			if (room && keepers) {
+				if (cnt0 == 0)
+					t->first = fp;
+				t->last = lp;
+				t->count = cnt0 + seg_total;
+			}
+			if (alive && !t->akey) {
+				t->akey = ak;
+				t->anode = an;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (__ballot(big && dst != nullptr)) {   // third pass: the big lanes write what the shadow leaves them
+		h.n = 0;
+		if (big && dst != nullptr)
+			(void)follow(a, h, node, run, s + a.D - 1, kWrite, M, dst);
+	}
+}
+
+// The carried state (a path that started before byte 0) and the state the last D-1
+// bytes lead to from the root: two short serial walks of the real DFA, one lane.
+__device__ void side_walks(const SieveArgs &a)
+{
+	{
+		uint32_t st = 0;
+		for (uint32_t x = a.n > a.D - 1 ? a.n - (a.D - 1) : 0u; x < a.n; x++)
+			st = a.cold[((size_t)st << 8) | a.text[x]];
+		a.misc[0] = st;
+	}
+	Tile t;
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.pad = 0;
+	uint32_t state = a.init_state, x = 0;   // x: next byte to consume
+	uint32_t run = 0;                        // known unary, non-final path ahead of 'state'
+	while (state != 0) {
+		if (x >= a.n) {
+			t.akey = 1;
+			t.anode = state;
+			break;
+		}
+		if (run && x + 16 <= a.n_pad) {
+			const uint32_t want = min(min(run, 16u), a.n - x);
+			const uint32_t k = min(agree16(a.in_byte + state + 1, a.text + x), want);
+			state += k;   // depth grows with every byte: the start stays where it is
+			x += k;
+			run -= k;
+			t.carry = x;
+			if (k == want)
+				continue;
+			run = 0;
+		}
+		const uint32_t c = a.text[x];
+		const uint4 rec = a.rec[state];
+		const uint32_t next = a.cold[((size_t)state << 8) | c];
+		if ((uint32_t)a.depth[next] < x + 2)
+			break;   // the state after byte x starts at or behind byte 0: a follower's business
+		run = ((rec.y & 0x1FFu) == 1 && (rec.x & 0xFFFFFFu) == next) ? rec.y >> 16 : 0u;
+		state = next;
+		t.carry = x + 1;
+		if (state >= a.F && x >= a.drop_before) {
+			if (t.count >= a.cap) {
+				t.gave_up = 1;
+				break;
+			}
+			a.lists[t.count] = make_uint2(x, (uint32_t)a.out[state]);
+			if (t.count == 0)
+				t.first = x;
+			t.last = x;
+			t.count++;
+		}
+		x++;
+	}
+	write_summary(a, t, 0);
+}
+
+// ------------------------------------------------------------------- K1 ---
+// The bulk pass.  Persistent workgroups keep the Bloom filter in LDS; a wave owns a tile
+// at a time, reads it 16 bytes per lane, tests one 3-gram per W bytes and writes the
+// samples the filter flags -- position and 3-gram -- to the tile's list in position order
+// (ranks from ballots: no scan, no LDS queue).  Nothing here waits on a dependent load.
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	constexpr uint32_t S = 16 / W;                              // samples per 16-byte group
+	constexpr uint32_t LOADS = 8;                               // groups per lane per sub-block
+	constexpr uint32_t SUB = LOADS * 1024;                      // bytes of a sub-block
+	const uint32_t nwaves = gridDim.x * kWaves;
+	const uint32_t n16 = a.n_pad >> 4;
+	const uint32_t *text32 = (const uint32_t *)a.text16;
+
+	uint4 w[LOADS];
+	uint32_t nx[LOADS];
+	// the groups of the sub-block at 'off' of 'tile': issued early, probed later
+	auto issue = [&](uint32_t tile, uint32_t off) {
+#pragma unroll
+		for (uint32_t j = 0; j < LOADS; j++) {
+			const uint32_t rel = off + j * 1024;
+			const uint32_t g16 = ((tile * a.tile_bytes + rel) >> 4) + lane;   // wraps only for tiles that do not exist
+			const bool ok = tile < a.ntiles && rel < a.tile_bytes && g16 < n16;
+			if (!ok) {
+				w[j] = make_uint4(0, 0, 0, 0);
+			} else if (a.nt & 1) {
+				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+				const v4u v = __builtin_nontemporal_load((const v4u *)&a.text16[g16]);
+				w[j] = make_uint4(v.x, v.y, v.z, v.w);
+			} else {
+				w[j] = a.text16[g16];
+			}
+			if (W <= 2)
+				nx[j] = (ok && g16 + 1 < n16) ? text32[(size_t)g16 * 4 + 4] : 0u;
+		}
+	};
+	uint32_t tile = blockIdx.x * kWaves + wv, off = 0;
+	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x * kWaves + wv) * 8 : nullptr;
+	if (stamp && lane == 0)
+		stamp[0] = __builtin_amdgcn_s_memrealtime();
+	{
+		// the filter first (it is needed first), then the text: both in flight before anything waits
+		constexpr uint32_t PER = (1u << acm::kSieveMaxLogWords) / 4 / kBlock;   // 16-byte pieces per thread, at most
+		const uint4 *src = (const uint4 *)a.bloom;
+		uint4 *dst = (uint4 *)bloom;
+		const uint32_t cnt = a.bloom_words / 4;
+		const uint32_t rot = (blockIdx.x * 61u) % cnt;   // the workgroups do not start on the same L2 channel
+		uint4 piece[PER];
+		uint32_t where[PER];
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++) {
+			const uint32_t i = threadIdx.x + k * kBlock;
+			uint32_t j = i + rot;
+			j = j >= cnt ? j - cnt : j;
+			where[k] = j;
+			piece[k] = src[i < cnt ? j : 0];   // always a load: a conditionally filled array would live in scratch
+		}
+		issue(tile, off);
+#pragma unroll
+		for (uint32_t k = 0; k < PER; k++)
+			if (threadIdx.x + k * kBlock < cnt)
+				dst[where[k]] = piece[k];
+	}
+	__syncthreads();
+	if (stamp && lane == 0)
+		stamp[1] = __builtin_amdgcn_s_memrealtime();
+	const uint32_t word_shift = 32 - a.bloom_log_words;
+	const unsigned long long lt = (1ull << lane) - 1ull;   // the lanes in front of this one
+
+	uint32_t qn = 0;   // samples of the current tile written so far
+	while (tile < a.ntiles) {
+		const uint32_t base = tile * a.tile_bytes + off;
+		uint2 *list = a.samples + (size_t)tile * a.scap;
+#pragma unroll
+		for (uint32_t j = 0; j < LOADS; j++) {
+			const uint32_t x[5] = { w[j].x, w[j].y, w[j].z, w[j].w, W <= 2 ? nx[j] : 0u };
+			const uint32_t pos0 = base + j * 1024 + lane * 16;
+			// samples whose 3-gram lies inside the text (none for groups that were not loaded)
+			const bool loaded = off + j * 1024 < a.tile_bytes && pos0 + 2 < a.n;
+			const uint32_t room = loaded ? (a.n - 2 - pos0 + W - 1) / W : 0u;
+			uint32_t gram[S], fj = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < S; k++) {
+				const uint32_t b = k * W, i = b / 4, sh = b % 4;
+				const uint32_t v = sh == 0 ? x[i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i], sh);
+				gram[k] = v & 0xFFFFFFu;
+				fj |= (k < room ? bloom_hit(bloom, gram[k], word_shift) : 0u) << k;
+			}
+			if (!__ballot(fj != 0))
+				continue;
+			// rank of sample (lane, k) among the flagged ones of this group row, lane-major
+			uint32_t before = 0, all = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < S; k++) {
+				const unsigned long long bk = __ballot((fj >> k) & 1u);
+				before += (uint32_t)__popcll(bk & lt);
+				all += (uint32_t)__popcll(bk);
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < S; k++)
+				if ((fj >> k) & 1u) {
+					const uint32_t at = qn + before + (uint32_t)__popc(fj & ((1u << k) - 1u));
+					list[at] = make_uint2(pos0 + k * W, gram[k]);
+				}
+			qn += all;
+		}
+		if (stamp && lane == 0 && stamp[2] == 0)
+			stamp[2] = __builtin_amdgcn_s_memrealtime();
+		const uint32_t cur = tile;
+		off += SUB;
+		if (off >= a.tile_bytes) {
+			off = 0;
+			tile += nwaves;
+		}
+		issue(tile, off);   // the next sub-block's loads fly while this one's flags are written
+		if (tile != cur) {
+			if (lane == 0)
+				a.scount[cur] = qn;
+			qn = 0;
+		}
+	}
+	if (stamp && lane == 0)
+		stamp[4] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ------------------------------------------------------------------- K2 ---
+// The checks.  A wave takes the sample lists of kTilesPerChecker consecutive tiles, one
+// behind the other, 64 samples a round (stage 1); what stage 1 finds to be trie paths it
+// follows 64 at a time (stage 2).  A few hundred waves, each a chain of dependent loads:
+// latency-bound, light on everything else -- it runs beside the next batch's bulk pass.
+// The last workgroup walks the carried state and the tail instead.
+template <int W>
+__global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
+{
+	__shared__ uint32_t q2[kCheckBlock / 64][3][kQ2Cap];
+	__shared__ Tile tstate[kCheckBlock / 64][kTilesPerChecker];
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (blockIdx.x == gridDim.x - 1) {
+		if (threadIdx.x == 0)
+			side_walks(a);
+		return;
+	}
+	const uint32_t tile0 = (blockIdx.x * (kCheckBlock / 64) + wv) * kTilesPerChecker;
+	if (tile0 >= a.ntiles)
+		return;
+	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x * (kCheckBlock / 64) + wv + 8192) * 8 : nullptr;
+	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
+	if (stamp && lane == 0)
+		stamp[0] = __builtin_amdgcn_s_memrealtime();
+	Tile *tiles = tstate[wv];
+	if (lane < kTilesPerChecker * (sizeof(Tile) / 4))
+		((uint32_t *)tiles)[lane] = 0;
+	FollowerQueue fq;
+	fq.start = q2[wv][0];
+	fq.node_slot = q2[wv][1];
+	fq.run = q2[wv][2];
+	fq.count = 0;
+	// the lists of this wave's tiles, one behind the other
+	uint32_t mycount = 0;
+	if (lane < kTilesPerChecker && tile0 + lane < a.ntiles)
+		mycount = a.scount[tile0 + lane];
+	uint32_t cum[kTilesPerChecker + 1];
+	cum[0] = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < kTilesPerChecker; k++)
+		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)k);
+	const uint32_t nsamples = cum[kTilesPerChecker];
+	__builtin_amdgcn_wave_barrier();
+	uint32_t r0 = 0;
+	for (;;) {
+		if (fq.count >= 64 || (r0 >= nsamples && fq.count > 0)) {   // stage 2: a round of followers
+			const uint32_t cnt = min(fq.count, 64u);
+			const bool act = lane < cnt;
+			const uint32_t s0 = act ? fq.start[lane] : 0u, ns = act ? fq.node_slot[lane] : 0u;
+			const uint32_t rn = act ? fq.run[lane] : 0u;
+			// what is left moves to the front of the queue
+			const uint32_t left = fq.count - cnt;
+			uint32_t m0 = 0, m1 = 0, m2 = 0;
+			if (lane < left) {
+				m0 = fq.start[cnt + lane];
+				m1 = fq.node_slot[cnt + lane];
+				m2 = fq.run[cnt + lane];
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (lane < left) {
+				fq.start[lane] = m0;
+				fq.node_slot[lane] = m1;
+				fq.run[lane] = m2;
+			}
+			for (uint32_t i = 64 + lane; i < left; i += 64) {   // more than 64 left: ascending copy is safe (i < cnt + i)
+				fq.start[i] = fq.start[cnt + i];
+				fq.node_slot[i] = fq.node_slot[cnt + i];
+				fq.run[i] = fq.run[cnt + i];
+				__builtin_amdgcn_wave_barrier();
+			}
+			fq.count = left;
+			stage2_round(a, tiles, tile0 + 1, s0, ns & 0xFFFFFFu, rn, ns >> 24, act, lane, dbg_levels);
+			continue;
+		}
+		if (r0 >= nsamples)
+			break;
+		const uint32_t idx = r0 + lane;
+		const bool act = idx < nsamples;
+		uint32_t slot = 0, before = 0;
+#pragma unroll
+		for (uint32_t k = 1; k < kTilesPerChecker; k++) {
+			slot += idx >= cum[k] ? 1u : 0u;
+			before = idx >= cum[k] ? cum[k] : before;
+		}
+		uint2 it = make_uint2(0, 0);
+		if (act)
+			it = a.samples[(size_t)(tile0 + slot) * a.scap + (idx - before)];
+		dbg_rounds++;
+		dbg_cands += min(nsamples - r0, 64u);
+		r0 += 64;
+		stage1_round<W>(a, fq, it.x, it.y, slot, act, lane);
+	}
+	if (lane < kTilesPerChecker && tile0 + lane < a.ntiles)   // the summaries of this wave's tiles
+		write_summary(a, tiles[lane], tile0 + lane + 1);
+	if (stamp && lane == 0) {
+		stamp[4] = __builtin_amdgcn_s_memrealtime();
+		stamp[5] = ((unsigned long long)dbg_rounds << 32) | dbg_cands;
+		stamp[6] = ((unsigned long long)dbg_levels << 32);
+	}
+}
 
 // exclusive scan (max or sum) of one value per thread over the workgroup; *total = the full reduction
 template <bool IS_MAX>
@@ -491,130 +883,199 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 	return IS_MAX ? max(before, excl) : before + excl;
 }
 
-__global__ __launch_bounds__(kEmitBlock) void k_sparse_emit(SparseArgs a)
+// Every workgroup works out the whole prefix (a few thousand 32-byte summaries, L2
+// resident) and copies its share of the records.
+__global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 {
 	__shared__ uint32_t lds[kEmitBlock / 64];
-	__shared__ uint32_t first_cell[kEmitBlock + 1];   // output cell of each workgroup's first kept hit (this pass)
-	__shared__ uint32_t first_kept[kEmitBlock];       // index of that hit in the workgroup's list
-	if (a.flags[0]) {   // a cap was hit: the chain pipeline behind this kernel produces the planes
-		if (threadIdx.x == 0 && a.giveups)
-			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__shared__ uint32_t s_base[kMaxTiles + 2];   // first output cell of each row
+	__shared__ uint32_t s_drop[kMaxTiles + 1];   // shadowed head of each row's list
+	__shared__ unsigned long long s_alive;
+	const uint32_t rows = a.ntiles + 1;
+	const uint32_t r0 = threadIdx.x * kRowsPerThread;
+	if (threadIdx.x == 0)
+		s_alive = ~0ull;
+	uint32_t E[kRowsPerThread], cnt[kRowsPerThread], first[kRowsPerThread], last[kRowsPerThread];
+	uint32_t tmax = 0;
+	bool gave = false;
+	unsigned long long alive = ~0ull;
+#pragma unroll
+	for (uint32_t i = 0; i < kRowsPerThread; i++) {
+		const uint32_t r = r0 + i;
+		uint4 s = make_uint4(0, 0, 0, 0);
+		uint2 al = make_uint2(0, 0);
+		if (r < rows) {
+			s = *(const uint4 *)(a.summary + (size_t)r * kSummaryWords);
+			al = *(const uint2 *)(a.summary + (size_t)r * kSummaryWords + 4);
+		}
+		E[i] = s.x;
+		cnt[i] = s.y;
+		first[i] = s.z;
+		last[i] = s.w;
+		gave |= s.y == kGaveUp;
+		tmax = max(tmax, s.x);
+		if (al.x)
+			alive = min(alive, ((unsigned long long)al.x << 32) | al.y);
+	}
+	if (__syncthreads_or(gave ? 1 : 0)) {   // cannot happen (geometry_for): say so instead of writing planes
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			*a.path_marker = kMarkerFailed;
+			a.pat_plane[0] = a.off_plane[0] = 0;
+		}
 		return;
 	}
-	uint32_t extent_before = 0, cells_before = 0;   // over the workgroups of earlier passes
-	for (uint32_t first = 0; first < a.nblocks; first += kEmitBlock) {
-		const uint32_t b = first + threadIdx.x;
-		const bool live = b < a.nblocks;
-		const uint32_t extent = live ? a.block_extent[b] : 0u;
-		const uint32_t staged = live ? a.block_hits[b] : 0u;
-		const uint2 *list = a.hit_list + (size_t)b * kMaxHits;
-		// the list is sorted: what an earlier workgroup's walker covers is a prefix of it.  Its first
-		// entries are fetched before 'covered' is known (one load level instead of a dependent loop)
-		uint2 head[4];
+	if (alive != ~0ull)
+		atomicMin(&s_alive, alive);
+	uint32_t all_max, all_cells;
+	uint32_t carry = block_exclusive<true>(tmax, lds, &all_max);
+	uint32_t drop[kRowsPerThread], kept_sum = 0;
 #pragma unroll
-		for (uint32_t i = 0; i < 4; i++)
-			head[i] = i < staged ? list[i] : make_uint2(0xFFFFFFFFu, 0u);
-		uint32_t pass_extent, pass_cells;
-		const uint32_t covered = max(extent_before, block_exclusive<true>(extent, lds, &pass_extent));
-		uint32_t dropped = 0;
-#pragma unroll
-		for (uint32_t i = 0; i < 4; i++)
-			dropped += (i < staged && head[i].x < covered) ? 1u : 0u;
-		if (dropped == 4)
-			while (dropped < staged && list[dropped].x < covered)
-				dropped++;
-		const uint32_t kept = staged - dropped;
-		const uint32_t cell = block_exclusive<false>(kept, lds, &pass_cells);
-		first_cell[threadIdx.x] = cell;
-		first_kept[threadIdx.x] = dropped;
-		if (threadIdx.x == 0)
-			first_cell[kEmitBlock] = pass_cells;
-		__syncthreads();
-		// one thread per output cell: find the workgroup it belongs to, copy the record
-		for (uint32_t c = threadIdx.x; c < pass_cells; c += kEmitBlock) {
-			uint32_t lo = 0;   // last workgroup whose first cell is <= c (those without hits share a cell with the next)
-#pragma unroll
-			for (uint32_t step = kEmitBlock / 2; step > 0; step >>= 1)
-				if (first_cell[lo + step] <= c)
-					lo += step;
-			const uint2 rec = a.hit_list[(size_t)(first + lo) * kMaxHits + first_kept[lo] + (c - first_cell[lo])];
-			const uint32_t d = cells_before + c;
-			if (d + 2 < a.plane_capacity) {
-				a.pat_plane[1 + d] = (int32_t)rec.y;
-				a.off_plane[1 + d] = (int32_t)rec.x + a.off_shift;
+	for (uint32_t i = 0; i < kRowsPerThread; i++) {
+		uint32_t d = 0;
+		if (cnt[i] && first[i] < carry) {
+			if (last[i] < carry) {
+				d = cnt[i];
+			} else {
+				const uint2 *list = a.lists + (size_t)(r0 + i) * a.cap;
+				while (d < cnt[i] && list[d].x < carry)
+					d++;
 			}
 		}
-		__syncthreads();
-		extent_before = max(extent_before, pass_extent);
-		cells_before += pass_cells;
+		drop[i] = d;
+		kept_sum += cnt[i] - d;
+		carry = max(carry, E[i]);
 	}
-	if (threadIdx.x == 0) {   // header and trailer cells
-		const uint32_t total_hits = cells_before;
-		uint32_t last;
-		const unsigned long long k = *a.keeper;
-		if (k != ~0ull)
-			last = (uint32_t)k;   // a walker was still going at the last byte
-		else                      // depth <= 2 at the end: the state is a function of the last two bytes
-			last = a.t2g[(uint32_t)a.text[a.n - 2] | ((uint32_t)a.text[a.n - 1] << 8)];
-		const int32_t last_ref = (int32_t)a.dev2ref[last];
-		uint32_t tail = total_hits + 1;
+	uint32_t cell = block_exclusive<false>(kept_sum, lds, &all_cells);
+#pragma unroll
+	for (uint32_t i = 0; i < kRowsPerThread; i++) {
+		const uint32_t r = r0 + i;
+		if (r < rows) {
+			s_base[r] = cell;
+			s_drop[r] = drop[i];
+			cell += cnt[i] - drop[i];
+		}
+	}
+	if (threadIdx.x == 0)
+		s_base[rows] = all_cells;
+	__syncthreads();
+	// one thread per output cell: find the row it belongs to, copy the record
+	for (uint32_t c = blockIdx.x * kEmitBlock + threadIdx.x; c < all_cells; c += gridDim.x * kEmitBlock) {
+		uint32_t lo = 0, hi = rows;   // the row r with s_base[r] <= c < s_base[r + 1]
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (s_base[mid] <= c)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		const uint2 rec = a.lists[(size_t)lo * a.cap + s_drop[lo] + (c - s_base[lo])];
+		if (c + 2 < a.plane_capacity) {
+			a.pat_plane[1 + c] = (int32_t)rec.y;
+			a.off_plane[1 + c] = (int32_t)rec.x + a.off_shift;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {   // header and trailer cells
+		const unsigned long long k = s_alive;
+		const uint32_t last_dev = k != ~0ull ? (uint32_t)k : a.misc[0];
+		const int32_t last_ref = (int32_t)a.dev2ref[last_dev];
+		uint32_t tail = all_cells + 1;
 		if (tail > a.plane_capacity - 1)
 			tail = a.plane_capacity - 1;
-		a.pat_plane[0] = (int32_t)total_hits;
-		a.off_plane[0] = (int32_t)total_hits;
+		a.pat_plane[0] = (int32_t)all_cells;
+		a.off_plane[0] = (int32_t)all_cells;
 		a.pat_plane[tail] = last_ref;
 		a.off_plane[tail] = last_ref;
+		*a.path_marker = (uint32_t)ACM_SCAN_MODE_SPARSE;
+		// a batch this dense in matches is the chain pipeline's: AUTO mode counts them (scan.hip, pick_sparse)
+		if (a.giveups && all_cells > a.n / kDenseDivisor)
+			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
 size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
 
+struct Geometry {
+	uint32_t tile_bytes, ntiles, cap, scap;
+};
+
+// Nothing overflows: a tile's sample list has room for every sample of the tile, its hit list for
+// one hit per text position the tile's followers can reach (the shadow rule leaves at most one).
+Geometry geometry_for(const acm_dfa *d, size_t n)
+{
+	Geometry g;
+	g.tile_bytes = kMinTile;
+	while ((n + g.tile_bytes - 1) / g.tile_bytes > kMaxTiles)
+		g.tile_bytes *= 2;
+	g.ntiles = (uint32_t)((n + g.tile_bytes - 1) / g.tile_bytes);
+	g.cap = g.tile_bytes + d->max_pattern_len + 8;
+	g.scap = g.tile_bytes / (d->sv_stride ? d->sv_stride : 1);
+	return g;
+}
+
 }  // namespace
 
 namespace acm {
 
-size_t sparse_workspace_bytes(size_t max_text)
+size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
 {
-	const size_t blocks = (max_text / 64 + 2) / kBlockWords + 2;
+	if (!d->sparse_ok)
+		return 0;
+	const Geometry g = geometry_for(d, max_text);   // tile size and cap grow with the text, the tile count is bounded
 	size_t o = 0;
-	o += align_up((max_text / 16 + 16) * 2, 256);   // mask
-	o += align_up(blocks * 4, 256) * 2;              // per-workgroup extent, hit count
-	o += align_up(blocks * kMaxHits * 8, 256);       // per-workgroup hit lists
-	o += 256;                                        // flags + keeper
+	o += align_up((size_t)(kMaxTiles + 1) * kSummaryWords * 4, 256);
+	o += align_up((size_t)(g.ntiles + 1) * g.cap * 8, 256);
+	o += align_up((size_t)g.ntiles * g.scap * 8 + 64, 256);
+	o += align_up((size_t)kMaxTiles * 4, 256);
+	o += 256;
 	return o;
 }
 
 int sparse_prepare(const acm_dfa *)
 {
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sparse_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
-	    (int)(acm::kBloomMaxWords * 4)));
+	const int lds = (int)((1u << acm::kSieveMaxLogWords) * 4);
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 	return ACM_OK;
 }
 
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    uint32_t *path_marker, hipStream_t s, const uint32_t **gate, hipEvent_t after_filter, hipEvent_t after_walk)
+    uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit)
 {
 	const size_t n = b->n;
-	SparseArgs a;
+	const Geometry g = geometry_for(d, n);
+	SieveArgs a;
 	memset(&a, 0, sizeof(a));
-	a.deep = d->d_deep;
+	a.bloom = d->d_sv_bloom;
+	a.bloom_log_words = d->sv_bloom_log_words;
+	a.bloom_words = 1u << d->sv_bloom_log_words;
+	a.gram = (const uint4 *)d->d_sv_gram;
+	a.gram_log_buckets = d->sv_gram_log_buckets;
+	a.gram_probes = d->sv_gram_probes;
+	a.prefix = (const uint4 *)d->d_sv_prefix;
+	a.prefix_log_slots = d->sv_prefix_log_slots;
+	a.prefix_probes = d->sv_prefix_probes;
+	a.rec = (const uint4 *)d->d_sv_rec;
+	a.edges = (const uint4 *)d->d_sv_edges;
+	a.report_state = b->report == ACM_REPORT_STATE ? 1 : 0;
+	a.in_byte = d->d_in_byte;
+	a.cold = d->d_cold;
+	a.depth = d->d_depth;
 	a.out = b->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
 	a.dev2ref = d->d_dev2ref;
-	a.in_byte = d->d_in_byte;
-	a.bloom = d->d_bloom;
-	a.bloom_log_words = d->bloom_log_words;
-	a.bloom_words = 1u << d->bloom_log_words;
-	a.t2g = d->d_t2g;
+	a.F = d->first_final;
+	a.D = d->sv_prefix_len;
 	a.text16 = (const uint4 *)b->d_text;
 	a.text = (const uint8_t *)b->d_text;
 	a.n = (uint32_t)n;
 	a.n_pad = (uint32_t)((n + 15) & ~(size_t)15);
-	a.F = d->first_final;
 	a.init_state = init_dev;
 	a.drop_before = (uint32_t)b->halo;
 	a.off_shift = (int32_t)b->offset_shift;
-	a.nwords = (uint32_t)((n + 63) / 64);
-	a.nblocks = (a.nwords + kBlockWords - 1) / kBlockWords;
+	a.tile_bytes = g.tile_bytes;
+	a.ntiles = g.ntiles;
+	a.cap = g.cap;
 	char *ws = (char *)sparse_ws;
 	size_t o = 0;
 	auto take = [&](size_t bytes) {
@@ -622,34 +1083,110 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		o += align_up(bytes, 256);
 		return p;
 	};
-	const size_t blocks = (n / 64 + 2) / kBlockWords + 2;
-	a.mask = (uint16_t *)take((n / 16 + 16) * 2);
-	a.block_extent = (uint32_t *)take(blocks * 4);
-	a.block_hits = (uint32_t *)take(blocks * 4);
-	a.hit_list = (uint2 *)take(blocks * kMaxHits * 8);
-	a.flags = (uint32_t *)take(256);
-	a.keeper = (unsigned long long *)(a.flags + 8);
+	a.summary = (uint32_t *)take((size_t)(kMaxTiles + 1) * kSummaryWords * 4);
+	a.lists = (uint2 *)take((size_t)(g.ntiles + 1) * g.cap * 8);
+	a.samples = (uint2 *)take((size_t)g.ntiles * g.scap * 8);
+	a.scount = (uint32_t *)take((size_t)g.ntiles * 4);
+	a.scap = g.scap;
+	a.misc = (uint32_t *)take(256);
 	a.pat_plane = b->d_pat_plane;
 	a.off_plane = b->d_off_plane;
 	a.plane_capacity = (uint32_t)(b->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : b->plane_capacity);
 	a.path_marker = path_marker;
 	a.giveups = d->d_giveups;
-	*gate = a.flags;
+	static unsigned long long *d_stamps = nullptr;
+	const bool want_stamps = getenv("ACM_SIEVE_STAMPS") != nullptr;
+	a.nt = getenv("ACM_SIEVE_NT") ? (uint32_t)atoi(getenv("ACM_SIEVE_NT")) : 1;   // non-temporal text loads: the tables stay in L2
+	const size_t stamp_words = (size_t)(8192 + 1024) * 8;
+	if (want_stamps) {
+		if (!d_stamps)
+			ACM_HIP_TRY(hipMalloc((void **)&d_stamps, stamp_words * 8));
+		ACM_HIP_TRY(hipMemsetAsync(d_stamps, 0, stamp_words * 8, s));
+		a.stamps = d_stamps;
+	}
 
-	// a small filter leaves room for two workgroups per CU (and for the other kernels' LDS)
+	// K1: persistent workgroups of 16 waves, a tile per wave at a time; a small filter leaves room
+	// for two workgroups per CU
 	const size_t lds = (size_t)a.bloom_words * 4;
-	const uint32_t per_cu = lds <= 64 * 1024 ? 2 : 1;
-	const uint32_t wave_iters = (a.n_pad / 16 + 8 + 63) / 64;
-	uint32_t fblocks = (wave_iters + kFilterBlock / 64 - 1) / (kFilterBlock / 64);
-	if (fblocks > (uint32_t)d->num_cus * per_cu)
-		fblocks = (uint32_t)d->num_cus * per_cu;
-	hipLaunchKernelGGL(k_sparse_filter, dim3(fblocks), dim3(kFilterBlock), lds, s, a);
-	if (after_filter)
-		ACM_HIP_TRY(hipEventRecord(after_filter, s));
-	hipLaunchKernelGGL(k_sparse_walk, dim3(a.nblocks), dim3(kWalkBlock), 0, s, a);
-	if (after_walk)
-		ACM_HIP_TRY(hipEventRecord(after_walk, s));
-	hipLaunchKernelGGL(k_sparse_emit, dim3(1), dim3(kEmitBlock), 0, s, a);
+	const uint32_t per_cu = lds <= 72 * 1024 ? 2 : 1;
+	uint32_t blocks = (g.ntiles + kWaves - 1) / kWaves;
+	if (blocks > (uint32_t)d->num_cus * per_cu)
+		blocks = (uint32_t)d->num_cus * per_cu;
+	// K2: a wave per kTilesPerChecker tiles, and one workgroup for the serial walks
+	const uint32_t cwaves = (g.ntiles + kTilesPerChecker - 1) / kTilesPerChecker;
+	const uint32_t cblocks = (cwaves + kCheckBlock / 64 - 1) / (kCheckBlock / 64) + 1;
+	switch (d->sv_stride) {
+	case 8: hipLaunchKernelGGL(k_sieve<8>, dim3(blocks), dim3(kBlock), lds, s, a); break;
+	case 4: hipLaunchKernelGGL(k_sieve<4>, dim3(blocks), dim3(kBlock), lds, s, a); break;
+	case 2: hipLaunchKernelGGL(k_sieve<2>, dim3(blocks), dim3(kBlock), lds, s, a); break;
+	default: hipLaunchKernelGGL(k_sieve<1>, dim3(blocks), dim3(kBlock), lds, s, a); break;
+	}
+	if (after_sieve)
+		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
+	switch (d->sv_stride) {
+	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
+	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
+	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
+	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
+	}
+	uint32_t eblocks = (uint32_t)(n >> 22);
+	eblocks = eblocks < 4 ? 4 : eblocks > 64 ? 64 : eblocks;
+	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks), dim3(kEmitBlock), 0, s, a);
+	if (after_emit)
+		ACM_HIP_TRY(hipEventRecord(after_emit, s));
+	if (want_stamps) {   // debugging aid: where the waves spend their time (100 MHz clock)
+		std::vector<unsigned long long> h(stamp_words);
+		ACM_HIP_TRY(hipStreamSynchronize(s));
+		ACM_HIP_TRY(hipMemcpy(h.data(), d_stamps, stamp_words * 8, hipMemcpyDeviceToHost));
+		unsigned long long t0 = ~0ull;
+		for (size_t i = 0; i < stamp_words / 8; i++)
+			if (h[i * 8])
+				t0 = std::min(t0, h[i * 8]);
+		auto report = [&](const char *what, size_t first, size_t count, const char *const *names) {
+			std::vector<double> col[5];
+			unsigned long long rounds = 0, cands = 0;
+			for (size_t i = first; i < first + count; i++) {
+				if (!h[i * 8])
+					continue;
+				for (int k = 0; k < 5; k++)
+					if (h[i * 8 + k])
+						col[k].push_back((double)(h[i * 8 + k] - t0) / 100.0);
+				rounds += h[i * 8 + 5] >> 32;
+				cands += h[i * 8 + 5] & 0xFFFFFFFFull;
+			}
+			for (int k = 0; k < 5; k++) {
+				std::sort(col[k].begin(), col[k].end());
+				if (col[k].empty())
+					continue;
+				fprintf(stderr, "[%s] %-10s min %7.2f  p50 %7.2f  p99 %7.2f  max %7.2f us (%zu waves)\n", what, names[k],
+				    col[k].front(), col[k][col[k].size() / 2], col[k][col[k].size() * 99 / 100], col[k].back(),
+				    col[k].size());
+			}
+			if (rounds)
+				fprintf(stderr, "[%s] stage-1 rounds %llu, samples %llu\n", what, rounds, cands);
+		};
+		const char *n1[5] = { "start", "filled", "probed", "", "end" };
+		const char *n2[5] = { "start", "", "", "", "end" };
+		report("sieve", 0, (size_t)blocks * kWaves, n1);
+		report("check", 8192, cwaves, n2);
+		{
+			std::vector<double> by[40];
+			for (size_t i = 8192; i < 8192 + cwaves; i++) {
+				if (!h[i * 8] || !h[i * 8 + 4])
+					continue;
+				const unsigned lv = (unsigned)(h[i * 8 + 6] >> 32);
+				by[lv < 39 ? lv : 39].push_back((double)(h[i * 8 + 4] - h[i * 8]) / 100.0);
+			}
+			for (int k = 0; k < 40; k++) {
+				if (by[k].empty())
+					continue;
+				std::sort(by[k].begin(), by[k].end());
+				fprintf(stderr, "[check] follow levels %2d: %5zu waves, start->end p50 %6.2f max %6.2f us\n", k, by[k].size(),
+				    by[k][by[k].size() / 2], by[k].back());
+			}
+		}
+		fprintf(stderr, "[sieve] tiles %u, tile bytes %u, bloom words %u\n", g.ntiles, g.tile_bytes, a.bloom_words);
+	}
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }

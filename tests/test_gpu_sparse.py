@@ -1,7 +1,8 @@
-"""The sparse pipeline (trigram filter -> candidate walks -> prefix max -> scatter, sparse.hip)
-against the oracle and against the chain pipeline: same planes, bit for bit, whichever path
-produced them -- including the texts on which it gives up and the chain pipeline takes over
-inside the same enqueue.
+"""The sparse pipeline (strided 3-gram sieve -> exact prefix check -> trie-path followers ->
+ordered emit, sparse.hip) against the oracle and against the chain pipeline: same planes, bit for
+bit, whichever pipeline produced them -- including texts that are all matches or one endless
+trie path, which the sparse pipeline handles itself (slowly) and AUTO mode learns to hand to the
+chain pipeline.
 """
 import numpy as np
 import pytest
@@ -85,8 +86,9 @@ def test_dense_candidates(gpu, setname, alphabet):
 
 
 def test_sparse_path_is_the_one_that_ran(gpu):
-    """On ordinary data the sparse kernels produce the planes (no silent fallback); on a text
-    that is one long deep run they give up and the chain pipeline redoes it."""
+    """The sparse kernels produce the planes themselves (there is no fallback behind them): on
+    ordinary data, on a repeated signature, on zero pages, and on a text that is one endless trie
+    path with a hit every byte or so (followers with more than four hits take the slow passes)."""
     name = "clamav2000"
     o = fixtures.oracle_for(name)
     pats = fixtures.patterns_of(name)
@@ -103,16 +105,18 @@ def test_sparse_path_is_the_one_that_ran(gpu):
     assert m.path_taken(text.size) == "sparse"
     p = pats[5]
     rep = np.frombuffer((p * ((1 << 18) // len(p) + 1))[:1 << 18], dtype=np.uint8)
-    assert_same(m.scan(rep), o.scan(rep))          # a deep run per repetition: still sparse
+    assert_same(m.scan(rep), o.scan(rep))          # a follower per repetition
+    assert m.path_taken(rep.size) == "sparse"
     zeros = np.zeros(1 << 18, dtype=np.uint8)
     assert_same(m.scan(zeros), o.scan(zeros))
+    assert m.path_taken(zeros.size) == "sparse"
     m.close()
     a, o = build(SMALL_SETS["nested"])
     m = Matcher(a, 0, max_text=1 << 18)
     m.set_mode("sparse")
-    endless = np.frombuffer(b"abc" * 80000, dtype=np.uint8)   # one deep run, a hit every byte or so
+    endless = np.frombuffer(b"abc" * 80000, dtype=np.uint8)   # one endless path, a hit every byte or so
     assert_same(m.scan(endless), o.scan(endless))
-    assert m.path_taken(endless.size) == "sparse->chain"
+    assert m.path_taken(endless.size) == "sparse"
     quiet = np.frombuffer(b"abd" * 80000, dtype=np.uint8)
     assert_same(m.scan(quiet), o.scan(quiet))
     assert m.path_taken(quiet.size) == "sparse"
@@ -196,9 +200,8 @@ def test_shard_halo_in_sparse_mode(gpu):
 
 
 def test_beyond_the_fused_block_limit(gpu):
-    """Above 128 MiB the block prefix max / prefix sum are separate single-workgroup kernels
-    (below, every block reduces the values in front of it itself): both arrangements agree with
-    the oracle."""
+    """129 MiB: tiles of 32 KiB, a wave of the bulk pass takes several sub-blocks per tile; and the
+    chain pipeline's separate scan launch over more than 8192 block totals."""
     name = "clamav2000"
     o = fixtures.oracle_for(name)
     pats = fixtures.patterns_of(name)
@@ -327,13 +330,13 @@ def test_gibibyte_buffer(gpu):
     m.close()
 
 
-def test_auto_mode_backs_off_when_sparse_keeps_giving_up(gpu):
-    """AUTO: after 16 sparse batches of which at least 8 were given up on (here: all), the next
-    64 go to the chain pipeline directly; then the sparse pipeline is tried again.  Results are
-    the oracle's throughout; a forced SPARSE mode never backs off."""
+def test_auto_mode_hands_dense_batches_to_the_chain_pipeline(gpu):
+    """AUTO: after 16 sparse batches of which at least 8 were dense in matches (here: all; more
+    than a record per 128 bytes), the next 64 go to the chain pipeline directly; then the sparse
+    pipeline is tried again.  Results are the oracle's throughout; a forced SPARSE mode stays."""
     a, o = build(SMALL_SETS["nested"])
     m = Matcher(a, 0, max_text=1 << 17)
-    endless = np.frombuffer(b"abc" * 40000, dtype=np.uint8)      # one deep run: sparse gives up
+    endless = np.frombuffer(b"abc" * 40000, dtype=np.uint8)      # a record every byte or so
     quiet = np.frombuffer(b"abd" * 40000, dtype=np.uint8)
     exp_endless, exp_quiet = o.scan(endless), o.scan(quiet)
     m.set_mode("auto")
@@ -341,16 +344,16 @@ def test_auto_mode_backs_off_when_sparse_keeps_giving_up(gpu):
     for i in range(16 + 64 + 2):
         assert_same(m.scan(endless), exp_endless)
         paths.append(m.path_taken(endless.size))
-    assert paths[:16] == ["sparse->chain"] * 16
+    assert paths[:16] == ["sparse"] * 16
     assert paths[16:80] == ["chain"] * 64
-    assert paths[80:] == ["sparse->chain"] * 2                    # trying again
+    assert paths[80:] == ["sparse"] * 2                           # trying again
     m.set_mode("sparse")
     for i in range(20):
         assert_same(m.scan(endless), exp_endless)
-        assert m.path_taken(endless.size) == "sparse->chain"
+        assert m.path_taken(endless.size) == "sparse"
     m.close()
     a, o = build(SMALL_SETS["nested"])
-    m = Matcher(a, 0, max_text=1 << 17)                           # a text that never gives up never backs off
+    m = Matcher(a, 0, max_text=1 << 17)                           # a quiet text stays on the sparse pipeline
     for i in range(40):
         assert_same(m.scan(quiet), exp_quiet)
         assert m.path_taken(quiet.size) == "sparse"
@@ -389,6 +392,6 @@ def test_real_binary_content(gpu):
                 assert_same(got, exp)
                 paths.append(m.path_taken(piece.size))
                 state = exp[2]
-        assert set(paths) <= {"sparse", "sparse->chain", "chain"}
+        assert set(paths) <= {"sparse", "chain"}
         print(name, os.path.basename(libs[-1]), paths)
         m.close()
