@@ -442,49 +442,51 @@ extern "C" void ocl_aho_match(struct clconf *cl, struct databuf *db, acsm_t *acs
 		stream_len += (size_t)db->h_sizes[i];
 	}
 
+	// the scan's scratch depends on the automaton (the databuf was created without one)
+	const size_t need = acm_scan_workspace_bytes(acsm->dfa, db->size);
+	if (need > db->ws_bytes) {
+		hipFree(db->ws);
+		db->ws_bytes = need;
+		db->ws = (void *)device_mem(need, "alloc scan workspace");
+	}
 	int rc;
 	if (packed) {
 		rc = acm_scan_async(acsm->dfa, db->d_data, stream_len, db->last_state, db->ws, db->ws_bytes,
 		    pat_plane, off_plane, db->results_comp_size, s);
 	} else {
-		// pack into the tail of the workspace-independent scratch: a
-		// second text buffer + the packed starts, allocated on demand
-		static thread_local struct {
-			void *text = nullptr;
-			int32_t *starts = nullptr;
-			size_t text_cap = 0, starts_cap = 0;
-		} scratch;
-		if (scratch.text_cap < round16(db->size) + 16) {
-			if (scratch.text)
-				hipFree(scratch.text);
-			scratch.text_cap = round16(db->size) + 16;
-			scratch.text = (void *)device_mem(scratch.text_cap, "alloc packed text");
+		// pack into a second text buffer owned by the databuf (freed by databuf_free); the packed
+		// starts go through a pinned twin that outlives the copy: no synchronisation here
+		if (db->pack_text_cap < round16(db->size) + 16) {
+			if (db->pack_text)
+				hipFree(db->pack_text);
+			db->pack_text_cap = round16(db->size) + 16;
+			db->pack_text = (void *)device_mem(db->pack_text_cap, "alloc packed text");
 		}
-		if (scratch.starts_cap < (size_t)chunks + 1) {
-			if (scratch.starts)
-				hipFree(scratch.starts);
-			scratch.starts_cap = db->max_chunks + 1;
-			scratch.starts = (int32_t *)device_mem(scratch.starts_cap * sizeof(int32_t),
-			    "alloc packed starts");
+		if (db->pack_starts_cap < (size_t)chunks + 1) {
+			if (db->pack_starts)
+				hipFree(db->pack_starts);
+			if (db->h_pack_starts)
+				hipHostFree(db->h_pack_starts);
+			db->pack_starts_cap = db->max_chunks + 1;
+			db->pack_starts = (int *)device_mem(db->pack_starts_cap * sizeof(int32_t), "alloc packed starts");
+			db->h_pack_starts = (int *)pinned(db->pack_starts_cap * sizeof(int32_t), "pin packed starts");
 		}
-		std::vector<int32_t> starts((size_t)chunks + 1);
 		size_t acc = 0;
 		for (int i = 0; i < chunks; i++) {
-			starts[i] = (int32_t)acc;
+			db->h_pack_starts[i] = (int32_t)acc;
 			acc += (size_t)db->h_sizes[i];
 		}
-		starts[chunks] = (int32_t)acc;
-		hip_or_die(hipMemcpyAsync(scratch.starts, starts.data(), starts.size() * sizeof(int32_t),
+		db->h_pack_starts[chunks] = (int32_t)acc;
+		hip_or_die(hipMemcpyAsync(db->pack_starts, db->h_pack_starts, ((size_t)chunks + 1) * sizeof(int32_t),
 		    hipMemcpyHostToDevice, s), "write packed starts");
-		hip_or_die(hipStreamSynchronize(s), "write packed starts");  // 'starts' dies at scope end
-		rc = acm_pack_chunks(scratch.text, db->d_data, (const int32_t *)db->d_indices,
-		    (const int32_t *)db->d_sizes, scratch.starts, chunks, s);
+		rc = acm_pack_chunks(db->pack_text, db->d_data, (const int32_t *)db->d_indices,
+		    (const int32_t *)db->d_sizes, db->pack_starts, chunks, s);
 		if (rc == ACM_OK)
-			rc = acm_scan_async(acsm->dfa, scratch.text, stream_len, db->last_state, db->ws,
+			rc = acm_scan_async(acsm->dfa, db->pack_text, stream_len, db->last_state, db->ws,
 			    db->ws_bytes, pat_plane, off_plane, db->results_comp_size, s);
 		if (rc == ACM_OK)
 			rc = acm_remap_offsets(off_plane, stream_len, (const int32_t *)db->d_indices,
-			    scratch.starts, chunks, s);
+			    db->pack_starts, chunks, s);
 	}
 	if (rc != ACM_OK)
 		die("ocl_aho_match_kernel: ERROR executing kernel");
@@ -582,6 +584,10 @@ extern "C" void databuf_free(struct databuf *db, int mapped, cl_command_queue qu
 	hipFree(db->d_results_comp);
 	hipFree(db->d_results2_comp);
 	hipFree(db->ws);
+	hipFree(db->pack_text);
+	hipFree(db->pack_starts);
+	if (db->h_pack_starts)
+		hipHostFree(db->h_pack_starts);
 	free(db);
 }
 

@@ -481,6 +481,11 @@ struct databuf {
 				 * planes (the reference's COMPACT_RESULTS
 				 * build, databuf.c:16); 0: bucket planes   */
 	int scanned;		/* planes on the device are current         */
+	void *pack_text;	/* device copy of a padded chunk list packed */
+	size_t pack_text_cap;	/* into one stream (ocl_aho_match), and the  */
+	int *pack_starts;	/* packed start of each chunk: device array  */
+	int *h_pack_starts;	/* and its pinned host twin                  */
+	size_t pack_starts_cap;
 };
 
 struct databuf *databuf_new(size_t max_chunks, size_t max_chunk_size,
