@@ -6,25 +6,32 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): input GB/s scanned (+ matches/s), 32 MB text x N ClamAV signatures.
-A step = one pass of the scan pipeline (walk -> probe -> resolve -> prefix sum -> scatter) over
-one 32 MiB batch already resident in HBM (for signature sets whose shortest pattern has 3 bytes,
-as here, the library's sparse pipeline: trigram filter -> candidate walks -> prefix max -> count ->
-scatter; --mode chain forces the general one).  Like the reference, which keeps -w worker threads in
+A step = one pass of the scan pipeline over one 32 MiB batch already resident in HBM: the
+library's sparse pipeline for signature sets whose shortest pattern has 3 bytes (strided 3-gram
+sieve -> exact prefix check -> trie-path followers -> ordered emit; three kernels), its chain
+pipeline otherwise (--mode forces one).  Like the reference, which keeps -w worker threads in
 flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144, :498-502),
-steps are issued round-robin on --workers HIP streams with private scratch, so the
-latency-bound tail of one batch overlaps the walk of the next.  With N > 1 GPUs the logical
-text is N x 32 MiB, rank g scans shard g (+ an (L-1)-byte halo), the DFA is replicated and
-the compact match planes of every group of --gather-rounds x --workers steps go to rank 0 in one
-RCCL gather (double-buffered: it overlaps the next group's scans).
-Weak scaling: 32 MiB per GPU.
+--workers host threads each drive a HIP stream with private scratch.  The steps rotate over
+--texts distinct 32 MiB texts (more than the 256 MiB Infinity Cache in total), so the text a
+step reads comes from HBM.  The timed region is --repeats blocks of --steps steps, each block
+bracketed by a barrier + device synchronisation; the line reports the median block.
 
-Prints ONE JSON line on rank 0.
+With N > 1 GPUs the logical text of a step is N x 32 MiB (weak scaling) or one 32 MiB text cut
+N ways (--scaling strong); rank g scans shard g (+ an (L-1)-byte halo), the DFA is replicated,
+and the compact match planes of all steps of a block go to rank 0 in ONE RCCL gather inside
+the timed block.
+
+Prints ONE JSON line on rank 0.  The headline is BASELINE.json configs[1] (clamav2000); at N = 1
+the line also carries sub-records for configs[2] (clamav15000) and configs[4] (sentiment), an
+end-to-end figure that includes the host-to-device copy, and the CPU baseline.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import numpy as np
@@ -35,6 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 SHARD = 32 << 20
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+L3_BYTES = 256 << 20        # Infinity Cache
 
 
 def log(rank, *a):
@@ -42,266 +50,297 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--sigs", type=int, default=2000, choices=[2000, 10000, 15000])
-    ap.add_argument("--max-len", type=int, default=-1, help="-m pattern length limit")
-    ap.add_argument("--chain", type=int, default=0, help="chain bytes (0 = auto)")
-    ap.add_argument("--plant", type=int, default=4096)
-    ap.add_argument("--workers", type=int, default=4, help="batches in flight (HIP streams)")
-    ap.add_argument("--chain-walks", action="store_true",
-                    help="chain the walk kernels of consecutive batches with events (acm_scan_batch_async); "
-                         "measured slower than letting the streams run free on MI355X")
-    ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
-                    help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
-    ap.add_argument("--graphs", action="store_true",
-                    help="replay the HIP graph the library captures for a repeating batch instead of "
-                         "launching every kernel of every step (acm_scan_set_graphs; measured neutral)")
-    ap.add_argument("--profile-every", type=int, default=8,
-                    help="record the library's HIP events (kernel durations for the roofline) on every K-th "
-                         "timed step; those steps are launched kernel by kernel, the others replay the graph")
-    ap.add_argument("--gather-rounds", type=int, default=4,
-                    help="N > 1: rounds of --workers steps whose match planes travel to rank 0 in one gather")
-    ap.add_argument("--cpl", type=int, default=0, help="chains per lane in the walk (2 or 4; 0 = default)")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    args = ap.parse_args()
+class Workload:
+    """Pattern set + corpus generator of one BASELINE.json config."""
 
-    # one hardware queue per batch in flight: with HIP's default of 4 queues per process the
-    # streams of 4 workers (+ torch's own) share queues and serialise (measured: 43 vs 27 us/step)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
+    def __init__(self, name, plant):
+        import synth
+        self.name = name
+        self.plant = plant
+        data = os.path.join(ROOT, "tests", "data")
+        if name.startswith("clamav"):
+            self.sigs = int(name[len("clamav"):])
+            self.pats = synth.load_hex_patterns(os.path.join(data, "clamav", "15000.txt"), self.sigs)
+            self.pattern_file = None
+            self.what = ("32 MiB per GPU of seeded uniform bytes + %d planted signatures x first %d ClamAV sigs"
+                         % (plant, self.sigs))
+            self.cap = 1 << 13
+            while self.cap < 2 * plant + 1024:
+                self.cap *= 2
+        elif name == "sentiment":
+            self.sigs = None
+            self.pats = None
+            self.pattern_file = os.path.join(data, "sentiment", "patterns_categorical.txt")
+            self.words = open(os.path.join(data, "sentiment", "top5000_words.txt")).read().split()
+            self.what = ("32 MiB of space-separated words, half of them from the sentiment vocabulary, x the "
+                         "4376 categorical sentiment patterns (apps/patterns.txt)")
+            self.cap = 1 << 21      # ~0.93 M records per 32 MiB
+        else:
+            raise SystemExit("unknown workload " + name)
 
+    def automaton(self):
+        from gpu_pattern_matching_amd import Automaton
+        aut = Automaton()
+        if self.pats is not None:
+            for i, p in enumerate(self.pats):
+                aut.add(p, i)
+        else:
+            aut.load_file(self.pattern_file, False, -1)
+        aut.compile()
+        return aut
+
+    def oracle(self):
+        import orc  # tests/orc.py -> oracle/ (checker + CPU baseline only)
+        o = orc.Oracle()
+        if self.pats is not None:
+            for i, p in enumerate(self.pats):
+                o.add(p, i)
+        else:
+            o.load(self.pattern_file)
+        o.compile()
+        return o
+
+    def text(self, seed, n=SHARD):
+        import synth
+        if self.pats is not None:
+            return synth.clamav_corpus(n, seed, self.pats, self.plant)
+        return synth.word_corpus(n, seed, self.words)
+
+
+class Pool:
+    """--workers host threads, parked between blocks (a thread per block would cost more than a step)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.go = threading.Barrier(n + 1)
+        self.done = threading.Barrier(n + 1)
+        self.job = None
+        self.err = []
+        self.threads = [threading.Thread(target=self._run, args=(i,), daemon=True) for i in range(n)]
+        for t in self.threads:
+            t.start()
+
+    def _run(self, i):
+        while True:
+            self.go.wait()
+            if self.job is None:
+                return
+            try:
+                self.job(i)
+            except Exception as e:      # surfaced by run()
+                self.err.append(e)
+            self.done.wait()
+
+    def run(self, job):
+        self.job = job
+        self.go.wait()
+        self.done.wait()
+        if self.err:
+            raise self.err[0]
+
+    def close(self):
+        self.job = None
+        self.go.wait()
+
+
+def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headline):
+    """Everything for one workload; returns the record (rank 0) or None."""
     import torch
     import torch.distributed as dist
-    # rehearsal mode for a one-GPU box: ACM_BENCH_BACKEND=gloo puts every rank on cuda:0 and
-    # moves the gather through host memory; the real multi-GPU run uses RCCL ("nccl")
-    backend = os.environ.get("ACM_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    import synth  # tests/synth.py: seeded corpus
-    from gpu_pattern_matching_amd import Automaton, Matcher, build, sharding
+    from gpu_pattern_matching_amd import Matcher, sharding
     from gpu_pattern_matching_amd._lib import check
-    build.build()          # no-op when libacmatch.so is current; raises if it cannot be built
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    rank, world, dev, args = ctx["rank"], ctx["world"], ctx["dev"], ctx["args"]
+    strong = args.scaling == "strong" and world > 1
 
-    # ---- automaton: first --sigs ClamAV signatures (clamav_sample_sigs/<N>.txt are prefixes) ----
-    sig_path = os.path.join(ROOT, "tests", "data", "clamav", "15000.txt")
-    pats = synth.load_hex_patterns(sig_path, args.sigs, args.max_len)
     t0 = time.perf_counter()
-    aut = Automaton()
-    for i, p in enumerate(pats):
-        aut.add(p, i)
-    aut.compile()
+    aut = wl.automaton()
     t_compile = time.perf_counter() - t0
-    L = aut.max_pattern_len
-    states = aut.num_states
-    matcher = Matcher(aut, local_rank, max_text=16, plane_capacity=2, stream=stream)
-    matcher.set_chain_bytes(args.chain)
+    L, states = aut.max_pattern_len, aut.num_states
+    matcher = Matcher(aut, ctx["local_rank"], max_text=16, plane_capacity=2)
     matcher.set_mode(args.mode)
-    graphs = matcher.set_graphs(args.graphs)
-    if args.cpl:
-        matcher.set_chains_per_lane(args.cpl)
     aut.close()
-    log(rank, "automaton: %d sigs, %d states, L=%d, compile %.2fs, device %.1f MB, hot rows %d" % (
-        len(pats), states, L, t_compile, matcher.device_bytes / 1e6, matcher.hot_rows))
+    log(rank, "%s: %d states, L=%d, compile %.2fs, device %.1f MB, sparse eligible: %s" % (
+        wl.name, states, L, t_compile, matcher.device_bytes / 1e6, matcher.sparse_eligible()))
 
-    # ---- text: logical text = world shards of 32 MiB; shard r = seeded corpus(seed 7 + r) ------
-    def shard_text(r):
-        return synth.clamav_corpus(SHARD, 7 + r, pats, args.plant)
+    # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
+    #      loads its range plus the halo in front of it -------------------------------------------
+    def shard(i, r):
+        return wl.text(7 + i * 64 + r)
 
-    total_bytes = SHARD * world
+    def logical(i):
+        return shard(i, 0) if (world == 1 or strong) else np.concatenate([shard(i, r) for r in range(world)])
+
+    total_bytes = SHARD if strong else SHARD * world
     plan = sharding.shard_plan(total_bytes, world, rank, L)
-    mine = shard_text(rank)
-    if plan["halo"]:
-        mine = np.concatenate([shard_text(rank - 1)[-plan["halo"]:], mine])
-    n_local = mine.size
-    assert n_local == plan["load_bytes"]
-    d_text = torch.zeros((n_local + 15) // 16 * 16, dtype=torch.uint8, device=dev)
-    d_text[:n_local] = torch.from_numpy(mine).to(dev)
+    n_local = plan["load_bytes"]
+    d_texts, h_texts = [], []
+    for i in range(ntexts):
+        if strong:
+            mine = shard(i, 0)[plan["load_begin"]:plan["end"]]
+        else:
+            mine = shard(i, rank)
+            if plan["halo"]:
+                mine = np.concatenate([shard(i, rank - 1)[-plan["halo"]:], mine])
+        assert mine.size == n_local
+        t = torch.zeros((n_local + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+        t[:n_local] = torch.from_numpy(mine).to(dev)
+        d_texts.append(t)
+        if i < 2:
+            h_texts.append(mine)
+    residency = "HBM" if ntexts * n_local > L3_BYTES else "Infinity Cache (%d MiB of texts <= 256 MiB)" % (
+        ntexts * n_local >> 20)
+
     ws_bytes = matcher.lib.acm_scan_workspace_bytes(matcher.dfa, n_local)
-    cap = 1 << 14                                   # cells per plane; 3.8k records expected
-    while cap < 2 * args.plant + 1024:
-        cap *= 2
-    W = max(1, args.workers)
-
-    class Worker:
-        def __init__(self):
-            self.stream = torch.cuda.Stream(device=dev)
-            self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            self.scanned = torch.cuda.Event()       # recorded behind the worker's latest scan
-
-    workers = [Worker() for _ in range(W)]
-    # Match planes of a group of G = --gather-rounds x W consecutive steps sit in one tensor and
-    # travel to rank 0 in ONE gather: a collective per step would cost more host time than the
-    # scan it follows.  Two such tensors, so the gather of one group overlaps the scans of the next.
-    G = W * max(1, args.gather_rounds)
-    planes = [torch.zeros((G, 2, cap), dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [[torch.empty((G, 2, cap), dtype=torch.int32, device=dev) for _ in range(world)]
-                for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    cap = wl.cap
+    W = max(1, workers)
+    K = max(W, steps)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
+    wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
+    # the check, else a ring of slots per worker
+    slots = K if (world > 1 or K * cap * 8 <= (512 << 20)) else min(K, max(W * 2, ntexts))
+    planes = torch.zeros((slots, 2, cap), dtype=torch.int32, device=dev)
+    gathered = [torch.empty_like(planes) for _ in range(world)] if (world > 1 and rank == 0) else None
     gather_stream = torch.cuda.Stream(device=dev)
-    gather_done = [None, None]                      # event behind the last gather of each tensor
-    open_group = {"buf": None, "slots": set()}      # scans issued but not gathered yet
-    # the walk kernels of consecutive batches are chained by events (batch k+1's walk starts when
-    # batch k's walk is done): only the walks serialise, everything behind them overlaps
-    walk_done = []
-    for _ in range(2 * W):
-        e = C.c_void_p()
-        check(matcher.lib.acm_rt_event_create(C.byref(e)), "acm_rt_event_create")
-        walk_done.append(e)
-    issued = [0]
-    torch.cuda.synchronize()
+    pe = max(1, args.profile_every)
 
-    def flush():
-        """Gather the planes of the group that is open (all of its scans are enqueued)."""
-        buf = open_group["buf"]
-        open_group["buf"], open_group["slots"] = None, set()
-        if buf is None or world == 1:
-            return
-        if backend == "nccl":
-            for wk in workers:                      # behind every worker's latest scan
-                gather_stream.wait_event(wk.scanned)
-            with torch.cuda.stream(gather_stream):
-                dist.gather(planes[buf], gather_list=gathered[buf] if rank == 0 else None, dst=0)
-                done = torch.cuda.Event()
-                done.record(gather_stream)
-            gather_done[buf] = done
-        else:   # rehearsal: through the host
-            for wk in workers:
-                wk.stream.synchronize()
-            host = planes[buf].cpu()
-            bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, gather_list=bufs, dst=0)
-            if rank == 0:
-                for g, h in zip(gathered[buf], bufs):
-                    g.copy_(h)
+    def batches(profile):
+        out = []
+        for k in range(K):
+            w, p = k % W, planes[k % slots]
+            out.append(matcher.make_batch(d_texts[k % ntexts], n_local, streams[w].cuda_stream, p[0], p[1], cap,
+                                          (wss[w], ws_bytes), halo=plan["halo"], offset_shift=plan["offset_shift"],
+                                          profile=profile and w == 0 and (k // W) % pe == 0))
+        return out
 
-    def step(k):
-        w, buf, slot = k % W, (k // G) & 1, k % G
-        wk = workers[w]
-        if open_group["buf"] is not None and (open_group["buf"] != buf or slot in open_group["slots"]):
-            flush()                                 # a new group begins
-        if gather_done[buf] is not None:            # the gather that last read this tensor:
-            wk.stream.wait_event(gather_done[buf])  # the worker's stream waits for it, not the host
-        p = planes[buf][slot]
-        i = issued[0]
-        issued[0] += 1
-        chain = args.chain_walks and W > 1
-        wait = walk_done[(i - 1) % len(walk_done)] if (chain and i > 0) else None
-        matcher.scan_async(d_text, n_local, 0, wk.stream.cuda_stream, p[0], p[1], cap, halo=plan["halo"],
-                           offset_shift=plan["offset_shift"], workspace=(wk.ws, ws_bytes),
-                           wait_before_walk=wait,
-                           record_after_walk=walk_done[i % len(walk_done)] if chain else None)
-        if world > 1:
-            wk.scanned.record(wk.stream)
-        open_group["buf"] = buf
-        open_group["slots"].add(slot)
-        if len(open_group["slots"]) == G:
-            flush()
+    plain, profiled = batches(False), batches(True)
+    pool = Pool(W) if (W > 1 and not args.no_threads) else None
+    enq = matcher.lib.acm_scan_batch_async
+    dfa = matcher.dfa
 
-    def drain():
-        flush()
-        gather_stream.synchronize()
+    def issue(bs, count):
+        """count steps, step k on worker k % W; every worker's steps come from its own host thread."""
+        def job(w):
+            for k in range(w, count, W):
+                rc = enq(dfa, C.byref(bs[k]))
+                if rc:
+                    check(rc, "acm_scan_batch_async")
+        t = time.perf_counter()
+        if pool is not None:
+            pool.run(job)
+        else:
+            for k in range(count):
+                rc = enq(dfa, C.byref(bs[k]))
+                if rc:
+                    check(rc, "acm_scan_batch_async")
+        return time.perf_counter() - t
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    drain()
-    fence()
-    pe = max(1, args.profile_every)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if k % pe == 0:
-            matcher.profile(True)
-            step(k)
-            matcher.profile(False)
-        else:
-            step(k)
-    t_issued = time.perf_counter() - t0      # host time to enqueue everything (not a result)
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    k1_ms, k2_ms, pipe_ms, launches = matcher.profile_read()
-    # the same kernels with ONE batch in flight (outside the timed region): how long the walk
-    # takes when it has the GPU to itself, for reading the roofline beside the shared figure
-    solo_k1_ms = solo_k2_ms = solo_pipe_ms = 0.0
-    solo_n = 0
-    matcher.profile(True)
-    if W > 1:
-        for k in range(0, 10 * W, W):
-            step(k)
-            drain()
-            torch.cuda.synchronize()
-        solo_k1_ms, solo_k2_ms, solo_pipe_ms, solo_n = matcher.profile_read()
-    matcher.profile(False)
-    path = matcher.path_taken(n_local, workers[0].stream.cuda_stream, workspace=(workers[0].ws.data_ptr(), ws_bytes))
+    def gather():
+        if not dist.is_initialized():
+            return
+        for s in streams:                               # behind every worker's scans
+            gather_stream.wait_stream(s)
+        with torch.cuda.stream(gather_stream):
+            if ctx["backend"] == "nccl":
+                dist.gather(planes, gather_list=(gathered or [torch.empty_like(planes)]) if rank == 0 else None, dst=0)
+            else:                                       # rehearsal on one GPU: through the host
+                gather_stream.synchronize()
+                host = planes.cpu()
+                bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, gather_list=bufs, dst=0)
+                if rank == 0 and gathered is not None:
+                    for g, h in zip(gathered, bufs):
+                        g.copy_(h)
 
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    issue(plain, min(K, max(warmup, W)))
+    gather()
+    fence()
+    blocks, host_issue = [], []
+    matcher.profile_read()
+    for rep in range(max(1, repeats)):
+        fence()
+        t0 = time.perf_counter()
+        host_issue.append(issue(profiled if rep == repeats - 1 else plain, K))
+        gather()
+        fence()
+        blocks.append(time.perf_counter() - t0)
+    k1_ms, k2_ms, pipe_ms, launches = matcher.profile_read()
+    elapsed = statistics.median(blocks)
+    host_planes = planes.cpu().numpy()      # the planes of the last timed block
+    gathered_host = [g.cpu().numpy() for g in gathered] if gathered is not None else None
+    # one batch in flight (outside the timed region): what the kernels take when they have the GPU
+    # to themselves
+    scratch = torch.zeros((2, cap), dtype=torch.int32, device=dev)
+    for i in range(12):
+        matcher.enqueue(matcher.make_batch(d_texts[i % ntexts], n_local, streams[0].cuda_stream, scratch[0], scratch[1],
+                                           cap, (wss[0], ws_bytes), halo=plan["halo"],
+                                           offset_shift=plan["offset_shift"], profile=True))
+        torch.cuda.synchronize()
+    s_k1, s_k2, s_pipe, s_n = matcher.profile_read()
+    path = matcher.path_taken(n_local, streams[0].cuda_stream, workspace=(wss[0].data_ptr(), ws_bytes))
+
+    red = dev if ctx["backend"] == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- results of the last step -------------------------------------------------------------
-    k_last = max(args.steps - 1, 0)
-    slot_last, last = k_last % G, (k_last // G) & 1
-    local = planes[last][slot_last].cpu().numpy()
-    m_local = int(local[0, 0])
+    # ---- end to end with the host-to-device copy: the reference's Mbps definition counts bytes
+    #      from the files to the results (ocl_aho_grep.c:580,598,614,628-630) ------------------------
+    e2e = None
+    if headline and world == 1 and not args.no_e2e:
+        pinned = [torch.from_numpy(np.ascontiguousarray(h)).pin_memory() for h in h_texts]
+        stage = [torch.zeros_like(d_texts[0]) for _ in range(W)]
+        ne = 24
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(ne):
+            w = k % W
+            with torch.cuda.stream(streams[w]):
+                stage[w][:n_local].copy_(pinned[k % len(pinned)], non_blocking=True)
+            matcher.scan_async(stage[w], n_local, 0, streams[w].cuda_stream, scratch[0], scratch[1], cap,
+                               workspace=(wss[w], ws_bytes))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e2e = {"value": round(SHARD * ne / dt / 1e9, 2), "unit": "GB/s", "steps": ne,
+               "what": "pinned host buffer -> hipMemcpyAsync -> scan, %d streams; PCIe included, file I/O not" % W}
+
+    # ---- parity: the planes of the last steps of the last block, every distinct text once -----------
+    last_k = [k for k in range(max(0, K - ntexts), K) if slots == K or k >= K - slots]
+    m_local = int(host_planes[(K - 1) % slots, 0, 0])
     m_total = m_local
     if world > 1:
-        t = torch.tensor([m_local], dtype=torch.int64, device=red_dev)
+        t = torch.tensor([m_local], dtype=torch.int64, device=red)
         dist.all_reduce(t)
         m_total = int(t.item())
-
-    out = None
+    parity, cpu, out = "not checked", None, None
     if rank == 0:
-        if world > 1:
-            offs, pids, last_state = sharding.merge_gathered([g[slot_last] for g in gathered[last]])
-        else:
-            offs, pids, last_state = sharding.merge_gathered([local])
-        assert offs.size == m_total
-
-        parity = "not checked"
-        cpu = None
-        if not args.no_verify or not args.no_cpu_baseline:
-            import orc  # tests/orc.py -> oracle/ (checker + CPU baseline only)
-            o = orc.Oracle()
-            for i, p in enumerate(pats):
-                o.add(p, i)
-            o.compile()
-            whole = mine if world == 1 else np.concatenate([shard_text(r) for r in range(world)])
-            if not args.no_verify:
-                epos, epat, elast = o.scan(whole)
-                ok = (np.array_equal(epos, offs) and np.array_equal(epat, pids) and elast == last_state)
-                parity = "bit-exact vs oracle serial scan (%d records, final state %d)" % (
-                    epos.size, elast) if ok else "MISMATCH"
-                if not ok:
-                    log(rank, "PARITY MISMATCH: gpu %d records / oracle %d" % (offs.size, epos.size))
-            if world == 1 and not args.no_cpu_baseline:
+        if verify or (headline and not args.no_cpu_baseline):
+            o = wl.oracle()
+            if verify:
+                ok, nrec = True, 0
+                for k in last_k:
+                    if gathered_host is not None:
+                        offs, pids, last_state = sharding.merge_gathered([g[k % slots] for g in gathered_host])
+                    else:
+                        offs, pids, last_state = sharding.merge_gathered([host_planes[k % slots]])
+                    epos, epat, elast = o.scan(logical(k % ntexts), cap=max(cap * world, 1 << 16))
+                    good = np.array_equal(epos, offs) and np.array_equal(epat, pids) and elast == last_state
+                    if not good:
+                        log(rank, "PARITY MISMATCH %s step %d: gpu %d records / oracle %d" % (
+                            wl.name, k, offs.size, epos.size))
+                    ok &= good
+                    nrec += epos.size
+                parity = ("bit-exact vs oracle serial scan on %d distinct texts (%d records)" % (len(last_k), nrec)
+                          if ok else "MISMATCH")
+            if headline and world == 1 and not args.no_cpu_baseline:
+                mine = h_texts[0]
                 best, reps, t_start = 1e30, 0, time.perf_counter()
                 while time.perf_counter() - t_start < args.cpu_seconds or reps < 2:
                     t1 = time.perf_counter()
@@ -312,73 +351,49 @@ def main():
                 t1 = time.perf_counter()
                 o.scan_threads(mine, ncpu)
                 t_all = time.perf_counter() - t1
-                cpu = {"value": round(SHARD / best / 1e9, 4), "unit": "GB/s", "cores": 1,
-                       "kind": "port",
-                       "sample": "oracle/acref.c serial walk of the reference-format int32 table over "
-                                 "the same 32 MiB text, best of %d passes (%.1f s of CPU work)" % (
+                cpu = {"value": round(SHARD / best / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                       "sample": "oracle/acref.c serial walk of the reference-format int32 table over one 32 MiB "
+                                 "text of the workload, best of %d passes (%.1f s of CPU work)" % (
                                      reps, time.perf_counter() - t_start),
                        "all_cores": {"value": round(SHARD / t_all / 1e9, 4), "cores": ncpu}}
             o.close()
 
-        # The roofline is quoted for the longest kernel of the pipeline that ran.  Every kernel of a
-        # pipeline is a stage over the same N text positions, so the units one launch processes are
-        # the N bytes of the batch and the algorithmic bytes are SURVEY 8(d)'s per-scan figure,
-        # N x 1 B of text + 8 B per record, whichever stage is the slowest (chain: k_spec_walk reads
-        # the text; sparse: k_sparse_filter reads the text and hands one candidate bit per byte to
-        # k_sparse_walk, which is latency bound on a few ten thousand dependent table walks).
-        L1 = max(launches, 1)
+        # The roofline is quoted for the kernel that reads the text (the bulk pass: k_sieve, or
+        # k_spec_walk of the chain pipeline): algorithmic bytes = N x 1 B of text + 8 B per record
+        #  over that kernel's average duration, HIP events on the worker's own stream
+        # inside the timed region.
         alg_bytes = n_local + 8 * m_local
-        if path == "chain":
-            kernels = [("k_spec_walk", k1_ms, solo_k1_ms)]
-        else:
-            kernels = [("k_sieve", k1_ms, solo_k1_ms), ("k_sieve_emit", k2_ms, solo_k2_ms)]
-        kname, kms, ksolo_ms = max(kernels, key=lambda t: t[1])
-        walk_s = kms / 1e3 / L1
-        achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
-        value = total_bytes * args.steps / elapsed / 1e9
-        # HBM bytes per launch of the walk kernel from the PMC passes of this same command
-        # (tests/run_pmc.sh -> tests/pmc_summarize.py -> profiles/r1_traffic.json); counters
-        # cannot be collected inside a timed run, so this is read back, never estimated
-        traffic = None
-        stage_traffic = {}
-        tfile = os.path.join(ROOT, "profiles", "r1_traffic_chain.json" if path == "chain" else "r1_traffic.json")
-        if os.path.exists(tfile) and args.sigs == 2000 and args.max_len < 0:
+        kname = "k_sieve" if path == "sparse" else "k_spec_walk"
+        L1 = max(launches, 1)
+        k_s = k1_ms / 1e3 / L1
+        achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
+        value = total_bytes * K / elapsed / 1e9
+        traffic, stage_traffic = None, {}
+        tfile = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % wl.name)
+        if os.path.exists(tfile):
             for name, rec in json.load(open(tfile)).items():
-                for k in kernels:
-                    if k[0] in name:
-                        stage_traffic[k[0]] = round(rec["hbm_bytes_per_launch"], 1)
+                stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
             traffic = stage_traffic.get(kname)
         out = {
-            "metric": "input_GB_per_s_scanned",
             "value": round(value, 3),
-            "unit": "GB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
+            "ms_per_step": round(elapsed / K * 1e3, 5),
+            "timed_region_ms": round(elapsed * 1e3, 3),
+            "blocks_ms": [round(b * 1e3, 3) for b in blocks],
             "config": {
-                "workload": "32 MiB per GPU of seeded uniform bytes + %d planted signatures x first %d "
-                            "ClamAV sigs%s (%d states, max len %d); scan -> ordered compact "
-                            "(offset, pattern) planes, gathered to rank 0" % (
-                                args.plant, args.sigs,
-                                "" if args.max_len < 0 else " (-m %d)" % args.max_len, states, L),
-                "text_bytes_per_gpu": SHARD,
-                "signatures": args.sigs,
+                "workload": "%s (%d states, max len %d); scan -> ordered compact (offset, pattern) planes%s" % (
+                    wl.what, states, L, ", gathered to rank 0" if world > 1 else ""),
+                "text_bytes_per_step": total_bytes,
+                "distinct_texts": ntexts,
+                "text_residency": residency,
                 "pipeline": path,
-                "hip_graphs": graphs,
-                "chain_bytes": matcher.set_chain_bytes(args.chain) or "auto",
                 "batches_in_flight": W,
+                "host_threads": W if pool is not None else 1,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                "parallelism": "text sharded %d-way, DFA replicated" % world,
+                "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
             },
-            "host_enqueue_us_per_step": round(t_issued / args.steps * 1e6, 2),
+            "host_enqueue_us_per_step": round(statistics.median(host_issue) / K * 1e6, 2),
             "matches_per_step": m_total,
-            "matches_per_s": round(m_total * args.steps / elapsed, 1),
+            "matches_per_s": round(m_total * K / elapsed, 1),
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 5),
             "parity": parity,
             "roofline": {
@@ -390,38 +405,132 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_us": round(walk_s * 1e6, 2),
-                "pipeline_us": round(pipe_ms / max(launches, 1) * 1e3, 2),
-                "kernels_us": {k[0]: round(k[1] / L1 * 1e3, 2) for k in kernels},
-                "stages": [{"kernel": k[0], "us": round(k[1] / L1 * 1e3, 2),
-                            "achieved": round(alg_bytes / (k[1] / 1e3 / L1) / 1e9, 1) if k[1] > 0 else None,
-                            "frac": round(alg_bytes / (k[1] / 1e3 / L1) / 1e9 / HBM_PEAK_GBS, 4) if k[1] > 0 else None,
-                            "traffic": stage_traffic.get(k[0])} for k in kernels],
+                "kernel_us": round(k_s * 1e6, 2),
+                "rest_of_pipeline_us": round(k2_ms / L1 * 1e3, 2),
+                "pipeline_us": round(pipe_ms / L1 * 1e3, 2),
                 "launches_timed": launches,
-                "note": "HIP events on the batch's own stream around the kernels of every %d-th step of the "
-                        "timed region; with %d batches in flight a kernel shares the GPU with the other "
+                "stage_traffic": stage_traffic or None,
+                "note": "HIP events on the worker's own stream around the kernels of every %d-th step of worker 0 in "
+                        "the last timed block; with %d batches in flight a kernel shares the GPU with the other "
                         "batches' kernels" % (pe, W),
             },
         }
-        if solo_n:
-            sw = ksolo_ms / 1e3 / solo_n
+        if s_n:
+            sk = s_k1 / 1e3 / s_n
             out["roofline_one_batch_in_flight"] = {
-                "kernel_us": round(sw * 1e6, 2),
-                "kernels_us": {k[0]: round(k[2] / solo_n * 1e3, 2) for k in kernels},
-                "pipeline_us": round(solo_pipe_ms / solo_n * 1e3, 2),
-                "achieved": round(alg_bytes / sw / 1e9, 2),
-                "frac": round(alg_bytes / sw / 1e9 / HBM_PEAK_GBS, 5),
-                "launches": solo_n,
+                "kernel_us": round(sk * 1e6, 2),
+                "rest_of_pipeline_us": round(s_k2 / s_n * 1e3, 2),
+                "pipeline_us": round(s_pipe / s_n * 1e3, 2),
+                "achieved": round(alg_bytes / sk / 1e9, 2),
+                "frac": round(alg_bytes / sk / 1e9 / HBM_PEAK_GBS, 5),
+                "launches": s_n,
             }
+        if e2e is not None:
+            out["e2e_with_h2d"] = e2e
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+    if pool is not None:
+        pool.close()
+    matcher.close()
+    return out
 
-    if world > 1:
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
+    ap.add_argument("--workload", default="clamav2000", choices=["clamav2000", "clamav10000", "clamav15000", "sentiment"])
+    ap.add_argument("--sub", default="clamav15000,sentiment",
+                    help="workloads reported as sub-records of the line (N = 1 only); '' for none")
+    ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
+    ap.add_argument("--plant", type=int, default=4096)
+    ap.add_argument("--workers", type=int, default=4, help="batches in flight: HIP streams, one host thread each")
+    ap.add_argument("--no-threads", action="store_true", help="issue every step from the main thread")
+    ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
+                    help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: 32 MiB per GPU (weak) or one 32 MiB text cut N ways (strong)")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP events around the kernels of every K-th step of worker 0 in the last timed block")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    # one hardware queue per batch in flight: with HIP's default of 4 queues per process the
+    # streams of the workers (+ torch's own) share queues and serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    # ACM_BENCH_BACKEND=gloo: rehearsal on a one-GPU box (every rank on cuda:0, gather through the
+    # host).  ACM_BENCH_NCCL1=1: initialise RCCL even at world size 1, so that the collective path
+    # runs where only one GPU is available.
+    backend = os.environ.get("ACM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1 or os.environ.get("ACM_BENCH_NCCL1"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    from gpu_pattern_matching_amd import build
+    build.build()          # no-op when libacmatch.so is current; raises if it cannot be built
+    ctx = {"rank": rank, "world": world, "local_rank": local_rank, "dev": torch.device("cuda", local_rank),
+           "backend": backend, "args": args}
+
+    head = run_workload(ctx, Workload(args.workload, args.plant), args.steps, args.warmup, args.repeats,
+                        max(1, args.texts), args.workers, not args.no_verify, True)
+    subs = {}
+    if world == 1 and args.sub:
+        for name in args.sub.split(","):
+            if not name or name == args.workload:
+                continue
+            rec = run_workload(ctx, Workload(name, args.plant), max(args.workers, args.steps // 4), args.warmup,
+                               min(3, args.repeats), min(4, max(1, args.texts)), args.workers, not args.no_verify, False)
+            if rec is not None:
+                subs[name] = rec
+
+    bad = False
+    if rank == 0:
+        out = {
+            "metric": "input_GB_per_s_scanned",
+            "value": head["value"],
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": max(args.workers, args.steps),
+            "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "repeats": max(1, args.repeats),
+        }
+        out.update({k: v for k, v in head.items() if k not in ("value", "ms_per_step")})
+        if subs:
+            out["sub_records"] = subs
+        print(json.dumps(out), flush=True)
+        bad = head["parity"] == "MISMATCH" or any(s["parity"] == "MISMATCH" for s in subs.values())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    matcher.close()
-    if out is not None and out["parity"] == "MISMATCH":
+    if bad:
         sys.exit(1)
 
 

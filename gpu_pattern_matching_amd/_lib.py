@@ -23,7 +23,8 @@ class ScanBatch(C.Structure):
     _fields_ = [("d_text", _vp), ("n", C.c_size_t), ("halo", C.c_size_t), ("offset_shift", C.c_long),
                 ("init_state", C.c_long), ("d_workspace", _vp), ("workspace_bytes", C.c_size_t),
                 ("d_pat_plane", _vp), ("d_off_plane", _vp), ("plane_capacity", C.c_size_t),
-                ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp), ("report", C.c_int)]
+                ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp), ("report", C.c_int),
+                ("profile", C.c_int)]
 
 
 REPORT_HEAD, REPORT_STATE = 0, 1
@@ -82,7 +83,7 @@ NATIVE_API = {
     "acm_exclusive_scan_i32": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "acm_compact_buckets": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "acm_bitonic_sort_u32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint, C.c_uint, C.c_uint, _vp]),
-    "acm_bucketize": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "acm_bucketize": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "acm_pack_chunks": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "acm_remap_offsets": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "acm_rt_set_device": (C.c_int, [C.c_int]),

@@ -240,6 +240,19 @@ class Matcher:
                                       plane_capacity if plane_capacity is not None
                                       else self.plane_capacity, st), "acm_scan_async")
 
+    def make_batch(self, d_text, n, stream, pat_plane, off_plane, plane_capacity, workspace, init_state=0, halo=0,
+                   offset_shift=0, report=0, profile=False):
+        """A reusable acm_scan_batch for enqueue(): a worker that scans with the same buffers over and
+        over builds its batches once and pays one foreign call per scan."""
+        return _lib.ScanBatch(_ptr(d_text), n, halo, offset_shift, init_state, _ptr(workspace[0]), workspace[1],
+                              _ptr(pat_plane), _ptr(off_plane), plane_capacity, stream, None, None, report,
+                              1 if profile else 0)
+
+    def enqueue(self, batch):
+        rc = self.lib.acm_scan_batch_async(self.dfa, C.byref(batch))
+        if rc:
+            check(rc, "acm_scan_batch_async")
+
     def fetch(self, stream=None):
         """(offsets u32[], patterns i32[], last_state) of the last scan."""
         st = stream if stream is not None else self.stream
@@ -386,7 +399,8 @@ def bucketize(pat_plane, off_plane, indices, sizes, max_results, stream=None):
     d_r.fill(0)
     d_r2.fill(0)
     check(lib.acm_bucketize(d_p.ptr, d_o.ptr, d_i.ptr, d_s.ptr, chunks, max_results, d_r.ptr,
-                            d_r2.ptr, stream), "acm_bucketize")
+                            d_r2.ptr, min(np.asarray(pat_plane).size, np.asarray(off_plane).size), stream),
+          "acm_bucketize")
     r = d_r.to_numpy(np.int32, cells, stream=stream)
     r2 = d_r2.to_numpy(np.int32, cells, stream=stream)
     for d in (d_p, d_o, d_i, d_s, d_r, d_r2):

@@ -128,6 +128,8 @@ struct Shared {
 	                           // also allocates in ocl_worker_ctx_init, before start_time)
 };
 
+constexpr size_t kAllFactor = 4;   // -A: records the expanded planes hold per text byte
+
 struct Buffer {   // one of the two staging buffers of a worker
 	unsigned char *h_data = nullptr;
 	int32_t *h_indices = nullptr, *h_sizes = nullptr, *file_ids = nullptr;
@@ -135,6 +137,8 @@ struct Buffer {   // one of the two staging buffers of a worker
 	void *d_data = nullptr, *d_indices = nullptr, *d_sizes = nullptr, *d_starts = nullptr;
 	void *d_results = nullptr, *d_results2 = nullptr, *d_pat = nullptr, *d_off = nullptr;
 	void *d_pat_all = nullptr, *d_off_all = nullptr, *d_expand_ws = nullptr;   // -A only
+	size_t all_cap = 0;          // cells of the -A planes
+	int32_t *h_all_count = nullptr;   // pinned: records the expansion produced
 	size_t expand_ws_bytes = 0;
 	void *d_packed = nullptr;
 	size_t chunks = 0, bytes = 0;
@@ -181,8 +185,14 @@ void buffer_alloc(Buffer &b, const Config &c)
 	CK(acm_rt_malloc(&b.d_off, (size + 2) * 4));
 	if (c.all_patterns) {
 		b.expand_ws_bytes = acm_expand_workspace_bytes(size);
-		CK(acm_rt_malloc(&b.d_pat_all, (size + 2) * 4));
-		CK(acm_rt_malloc(&b.d_off_all, (size + 2) * 4));
+		// every pattern of every final state's list: more records than text bytes when patterns nest
+		// (aaa, aaaa, aaaaa over a run of a's); the planes hold kAllFactor per byte, beyond that the
+		// buffer is reported as an error (collect), never overrun
+		b.all_cap = size * kAllFactor + 2;
+		CK(acm_rt_host_alloc((void **)&b.h_all_count, 64));
+		*b.h_all_count = 0;
+		CK(acm_rt_malloc(&b.d_pat_all, b.all_cap * 4));
+		CK(acm_rt_malloc(&b.d_off_all, b.all_cap * 4));
 		CK(acm_rt_malloc(&b.d_expand_ws, b.expand_ws_bytes));
 	}
 }
@@ -256,7 +266,7 @@ void submit(Worker &w, Buffer &b)
 	CK(acm_rt_memcpy_h2d(b.d_data, b.h_data, (b.bytes + 15) & ~(size_t)15, s));
 	CK(acm_rt_memcpy_h2d(b.d_indices, b.h_indices, (size_t)chunks * 4, s));
 	CK(acm_rt_memcpy_h2d(b.d_sizes, b.h_sizes, (size_t)chunks * 4, s));
-	const size_t cap = (size_t)c.global_ws * c.chunk + 2;
+	size_t cap = (size_t)c.global_ws * c.chunk + 2;
 	const void *text = b.d_data;
 	if (!packed) {   // padded chunk list: scan the chunks' bytes back to back
 		CK(acm_rt_memcpy_h2d(b.d_starts, b.starts.data(), ((size_t)chunks + 1) * 4, s));
@@ -282,15 +292,17 @@ void submit(Worker &w, Buffer &b)
 		sb.report = ACM_REPORT_STATE;
 		CK(acm_scan_batch_async(w.sh->dfa, &sb));
 		CK(acm_expand_matches_async(w.sh->dfa, pat, off, cap - 2, (int32_t *)b.d_pat_all, (int32_t *)b.d_off_all,
-		    cap, b.d_expand_ws, b.expand_ws_bytes, s));
+		    b.all_cap, b.d_expand_ws, b.expand_ws_bytes, s));
 		pat = (int32_t *)b.d_pat_all;
 		off = (int32_t *)b.d_off_all;
+		cap = b.all_cap;
+		CK(acm_rt_memcpy_d2h(b.h_all_count, pat, 4, s));
 	}
 	if (!packed)
-		CK(acm_remap_offsets(off, stream_len, (const int32_t *)b.d_indices,
+		CK(acm_remap_offsets(off, cap - 2, (const int32_t *)b.d_indices,
 		    (const int32_t *)b.d_starts, chunks, s));
 	CK(acm_bucketize(pat, off, (const int32_t *)b.d_indices,
-	    (const int32_t *)b.d_sizes, chunks, c.max_results, (int32_t *)b.d_results, (int32_t *)b.d_results2, s));
+	    (const int32_t *)b.d_sizes, chunks, c.max_results, (int32_t *)b.d_results, (int32_t *)b.d_results2, cap, s));
 	const size_t cells = (size_t)c.max_results * chunks + 1;
 	CK(acm_rt_memcpy_d2h(b.h_results, b.d_results, cells * 4, s));
 	CK(acm_rt_memcpy_d2h(b.h_results2, b.d_results2, cells * 4, s));
@@ -301,6 +313,11 @@ void collect(Worker &w, Buffer &b)
 {
 	const Config &c = w.sh->cfg;
 	CK(acm_rt_stream_sync(w.stream));
+	if (c.all_patterns && b.h_all_count && (size_t)*b.h_all_count > b.all_cap - 2) {
+		fprintf(stderr, "ERROR: -A produced %d records for one buffer, the planes hold %zu; use a smaller -G/-B\n",
+		    *b.h_all_count, b.all_cap - 2);
+		exit(1);
+	}
 	const size_t chunks = b.chunks;
 	const int R = c.max_results;
 	w.last_state = b.h_results[chunks * R];
@@ -354,9 +371,19 @@ void *worker_main(void *arg)
 	const int nfiles = (int)sh.files.size();
 	int cur = w.id, filling = 0;
 	bool in_flight = false;
+	// text mode: one FILE per input, opened once (follow mode comes back to the same inputs
+	// every millisecond: a fresh fdopen per visit would leak a stdio buffer each time)
+	std::vector<FILE *> fps(c.text_mode ? (size_t)nfiles : 0, nullptr);
+	auto stream_of = [&](int f) -> FILE * {
+		if (!fps[(size_t)f])
+			fps[(size_t)f] = fdopen(sh.fds[f], "r");
+		else
+			clearerr(fps[(size_t)f]);   // past an EOF seen earlier: data may have been appended
+		return fps[(size_t)f];
+	};
 	FILE *fp = nullptr;
 	if (cur < nfiles && c.text_mode)
-		fp = fdopen(sh.fds[cur], "r");
+		fp = stream_of(cur);
 	const size_t G = (size_t)c.global_ws, size = G * (size_t)c.chunk;
 
 	while (cur < nfiles) {
@@ -372,7 +399,13 @@ void *worker_main(void *arg)
 		bool file_done = (got == 0) && !full;
 		if (file_done) {   // current file exhausted: next one of this worker
 			if (!c.follow) {
-				if (fp) { fclose(fp); fp = nullptr; } else close(sh.fds[cur]);
+				if (fp) {
+					fclose(fp);
+					fps[(size_t)cur] = nullptr;
+					fp = nullptr;
+				} else {
+					close(sh.fds[cur]);
+				}
 			}
 			cur += c.threads;
 			if (cur >= nfiles && c.follow && !g_terminate) {
@@ -380,7 +413,7 @@ void *worker_main(void *arg)
 				usleep(1000);
 			}
 			if (cur < nfiles && c.text_mode)
-				fp = fdopen(sh.fds[cur], "r");
+				fp = stream_of(cur);
 		}
 		const bool last = cur >= nfiles || g_terminate;
 		if (b.chunks > 0 && (full || last || (c.follow && file_done))) {

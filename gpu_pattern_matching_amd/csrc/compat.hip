@@ -493,7 +493,7 @@ extern "C" void ocl_aho_match(struct clconf *cl, struct databuf *db, acsm_t *acs
 	if (chunks > 0) {
 		rc = acm_bucketize(pat_plane, off_plane, (const int32_t *)db->d_indices,
 		    (const int32_t *)db->d_sizes, chunks, db->max_results, (int32_t *)db->d_results,
-		    (int32_t *)db->d_results2, s);
+		    (int32_t *)db->d_results2, db->results_comp_size, s);
 		if (rc != ACM_OK)
 			die("ocl_aho_match_kernel: ERROR executing kernel");
 	}

@@ -75,6 +75,7 @@ struct acm_dfa {
 	static constexpr size_t kMaxGraphs = 32;
 	mutable bool use_graphs = false;     // opt-in: measured neutral on this stack
 	mutable std::vector<GraphEntry> graphs;
+	mutable std::vector<void *> parked_graphs;   // evicted execs, destroyed by acm_dfa_release
 	mutable std::mutex graph_mutex;
 	mutable uint64_t graph_tick = 0;
 
@@ -83,4 +84,5 @@ struct acm_dfa {
 	mutable bool profile = false;
 	mutable std::vector<void *> profile_events;
 	mutable std::vector<void *> profile_pool;   // idle events, reused
+	mutable std::mutex profile_mutex;
 };

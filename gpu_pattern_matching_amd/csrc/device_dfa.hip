@@ -356,9 +356,12 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->arena);
 		if (d->h_giveups)
 			hipHostFree(d->h_giveups);
+		(void)hipDeviceSynchronize();   // no exec is destroyed under a launch
 		for (auto &g : d->graphs)
 			if (g.exec)
 				hipGraphExecDestroy((hipGraphExec_t)g.exec);
+		for (void *e : d->parked_graphs)
+			hipGraphExecDestroy((hipGraphExec_t)e);
 		for (void *e : d->profile_events)
 			hipEventDestroy((hipEvent_t)e);
 		for (void *e : d->profile_pool)

@@ -236,15 +236,18 @@ __device__ __forceinline__ uint32_t lower_bound_i32(const int32_t *a, uint32_t n
 	return lo;
 }
 
+// 'cap' = cells of a plane: a plane whose count exceeds cap - 2 holds the first cap - 2 records
+// and its trailer in the last cell (that is how the scan and expand kernels write it)
 __global__ void k_bucketize(const int32_t *pat_plane, const int32_t *off_plane,
     const int32_t *indices, const int32_t *sizes, int chunks, int max_results, int32_t *results,
-    int32_t *results2)
+    int32_t *results2, uint32_t cap)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t m = (uint32_t)pat_plane[0];
+	const uint32_t full = (uint32_t)pat_plane[0];
+	const uint32_t m = min(full, cap - 2), tail = min(full + 1, cap - 1);
 	if (i == 0) {
-		results[(size_t)chunks * max_results] = pat_plane[m + 1];   // last state
-		results2[(size_t)chunks * max_results] = pat_plane[m + 1];
+		results[(size_t)chunks * max_results] = pat_plane[tail];   // last state
+		results2[(size_t)chunks * max_results] = pat_plane[tail];
 	}
 	if (i >= chunks)
 		return;
@@ -280,9 +283,9 @@ __global__ __launch_bounds__(256) void k_pack_chunks(uint8_t *dst, const uint8_t
 }
 
 __global__ void k_remap_offsets(int32_t *off_plane, const int32_t *indices,
-    const int32_t *packed_start, int chunks)
+    const int32_t *packed_start, int chunks, uint32_t max_records)
 {
-	const uint32_t m = (uint32_t)off_plane[0];
+	const uint32_t m = min((uint32_t)off_plane[0], max_records);
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= m)
 		return;
@@ -322,7 +325,8 @@ extern "C" int acm_remap_offsets(int32_t *d_off_plane, size_t max_records, const
 	if (max_records == 0)
 		return ACM_OK;
 	hipLaunchKernelGGL(k_remap_offsets, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0,
-	    (hipStream_t)stream, d_off_plane, d_indices, d_packed_start, chunks);
+	    (hipStream_t)stream, d_off_plane, d_indices, d_packed_start, chunks,
+	    (uint32_t)(max_records > 0xFFFFFFFEul ? 0xFFFFFFFEul : max_records));
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }
@@ -481,13 +485,14 @@ extern "C" int acm_bitonic_sort_u32(uint32_t *d_key_dst, uint32_t *d_val_dst,
 
 extern "C" int acm_bucketize(const int32_t *d_pat_plane, const int32_t *d_off_plane,
     const int32_t *d_indices, const int32_t *d_sizes, int chunks, int max_results,
-    int32_t *d_results, int32_t *d_results2, void *stream)
+    int32_t *d_results, int32_t *d_results2, size_t plane_capacity, void *stream)
 {
 	if (!d_pat_plane || !d_off_plane || !d_indices || !d_sizes || !d_results || !d_results2 ||
-	    chunks <= 0 || max_results <= 0)
+	    chunks <= 0 || max_results <= 0 || plane_capacity < 2)
 		return acm::fail(ACM_ERR_ARG, "acm_bucketize: bad arguments");
 	hipLaunchKernelGGL(k_bucketize, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-	    d_pat_plane, d_off_plane, d_indices, d_sizes, chunks, max_results, d_results, d_results2);
+	    d_pat_plane, d_off_plane, d_indices, d_sizes, chunks, max_results, d_results, d_results2,
+	    (uint32_t)(plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : plane_capacity));
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }

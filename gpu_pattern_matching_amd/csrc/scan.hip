@@ -905,7 +905,7 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 	if (!batch)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: null batch");
 	const bool sparse = d && pick_sparse(d, batch->n);
-	if (!d || !d->use_graphs || d->profile || !batch->stream || batch->wait_before_walk ||
+	if (!d || !d->use_graphs || d->profile || batch->profile || !batch->stream || batch->wait_before_walk ||
 	    batch->record_after_walk || batch->n == 0)
 		return enqueue_batch(d, batch, sparse);
 	hipStream_t s = (hipStream_t)batch->stream;
@@ -924,8 +924,10 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 				for (size_t i = 1; i < d->graphs.size(); i++)
 					if (d->graphs[i].last_use < d->graphs[oldest].last_use)
 						oldest = i;
+				// its last launch may still be running: an exec is only ever destroyed by
+				// acm_dfa_release; an evicted one is parked until then
 				if (d->graphs[oldest].exec)
-					hipGraphExecDestroy((hipGraphExec_t)d->graphs[oldest].exec);
+					d->parked_graphs.push_back(d->graphs[oldest].exec);
 				d->graphs.erase(d->graphs.begin() + (long)oldest);
 			}
 			acm_dfa::GraphEntry fresh;
@@ -980,12 +982,7 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 			}
 		if (!stored) {   // evicted, or another thread was quicker
 			ACM_HIP_TRY(hipGraphLaunch(exec, s));
-			// cannot destroy while in flight: park it in the list under a key nobody asks for
-			acm_dfa::GraphEntry parked;
-			memset(&parked.key, 0xFF, sizeof(parked.key));
-			parked.exec = (void *)exec;
-			parked.last_use = 0;
-			d->graphs.push_back(parked);
+			d->parked_graphs.push_back((void *)exec);   // cannot be destroyed while in flight
 			return ACM_OK;
 		}
 	}
@@ -1102,7 +1099,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 	}
 
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-	if (d->profile) {
+	const bool profile = d->profile || batch->profile;
+	if (profile) {
+		std::lock_guard<std::mutex> lock(d->profile_mutex);
 		for (auto &e : ev) {
 			if (!d->profile_pool.empty()) {  // recycled: no create/destroy in a timed loop
 				e = (hipEvent_t)d->profile_pool.back();
@@ -1114,7 +1113,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 	}
 	if (batch->wait_before_walk)
 		ACM_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)batch->wait_before_walk, 0));
-	if (d->profile)
+	if (profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
 	if (sparse) {   // three kernels of its own; it always produces the planes
@@ -1123,8 +1122,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 			return rc;
 		if (batch->record_after_walk)
 			ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
-		if (d->profile) {
+		if (profile) {
 			ACM_HIP_TRY(hipEventRecord(ev[3], s));
+			std::lock_guard<std::mutex> lock(d->profile_mutex);
 			for (auto e : ev)
 				d->profile_events.push_back((void *)e);
 		}
@@ -1135,7 +1135,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 		return rc;
 	if (batch->record_after_walk)
 		ACM_HIP_TRY(hipEventRecord((hipEvent_t)batch->record_after_walk, s));
-	if (d->profile) {   // the walk is the first stage, there is no second
+	if (profile) {   // the walk is the first stage, there is no second
 		ACM_HIP_TRY(hipEventRecord(ev[1], s));
 		ACM_HIP_TRY(hipEventRecord(ev[2], s));
 	}
@@ -1159,8 +1159,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 	else
 		hipLaunchKernelGGL(k_scatter_all<2>, dim3(nb), dim3(kBlock2), 0, s, a);
 	ACM_HIP_TRY(hipGetLastError());
-	if (d->profile) {
+	if (profile) {
 		ACM_HIP_TRY(hipEventRecord(ev[3], s));
+		std::lock_guard<std::mutex> lock(d->profile_mutex);
 		for (auto e : ev)
 			d->profile_events.push_back((void *)e);
 	}
@@ -1184,6 +1185,7 @@ extern "C" int acm_scan_profile_read(acm_dfa *d, double *first_ms, double *secon
 		return acm::fail(ACM_ERR_ARG, "acm_scan_profile_read: null dfa");
 	double first = 0, second = 0, pipe = 0;
 	int n = 0;
+	std::lock_guard<std::mutex> lock(d->profile_mutex);
 	for (size_t i = 0; i + 3 < d->profile_events.size(); i += 4) {
 		hipEvent_t e[4];
 		for (int k = 0; k < 4; k++)

@@ -72,7 +72,7 @@ using acm_dev::agree16;
 
 constexpr int kBlock = 1024;               // threads of a k_sieve workgroup
 constexpr int kWaves = kBlock / 64;
-constexpr uint32_t kTilesPerChecker = 8;   // tiles whose flagged samples one wave of k_sieve_check takes
+constexpr uint32_t kTilesPerChecker = 4;   // tiles whose flagged samples one wave of k_sieve_check takes
 constexpr int kCheckBlock = 64;            // threads of a k_sieve_check workgroup
 constexpr uint32_t kQ2Cap = 64 + 64 * 8;   // followers a checker queues: what a round leaves + 64 samples x 8 offsets
 constexpr uint32_t kMinTile = 1024;        // bytes; one 16-byte group per lane
@@ -82,7 +82,8 @@ constexpr uint32_t kGaveUp = 0xFFFFFFFFu;  // hit count of a tile whose list was
 constexpr uint32_t kMarkerFailed = 0xDEADu; // path marker of a scan that did not produce planes
 constexpr uint32_t kDenseDivisor = 128;    // more than a record per this many bytes: a dense batch
 constexpr int kEmitBlock = 1024;
-constexpr uint32_t kRowsPerThread = (kMaxTiles + 1 + kEmitBlock - 1) / kEmitBlock;
+constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // checker waves + the carried-state walker
+constexpr uint32_t kRowsPerThread = (kMaxRows + kEmitBlock - 1) / kEmitBlock;
 
 struct SieveArgs {
 	// tables
@@ -107,21 +108,36 @@ struct SieveArgs {
 	uint32_t init_state, drop_before;
 	int32_t off_shift;
 	// geometry
-	uint32_t tile_bytes, ntiles, cap;
+	uint32_t tile_bytes, ntiles, cap, nrows;   // nrows: checker waves + 1
 	// workspace
+	uint2 *shead, *lhead;   // [ntiles][kSampleHead], [nrows][kHitHead]: the first entries of the lists below
 	uint2 *samples;      // [ntiles][scap] {position, 3-gram} of the samples the filter flagged, ascending
 	uint32_t *scount;    // [ntiles] how many (kGaveUp: more than scap)
 	uint32_t scap;
-	uint32_t *summary;   // [ntiles + 1][kSummaryWords]; row 0: the carried-state walker
-	uint2 *lists;        // [ntiles + 1][cap] {position, plane value}, ascending
+	uint32_t *summary;   // [nrows][kSummaryWords]; row 0: the carried-state walker, row 1 + w: checker wave w
+	uint2 *lists;        // [nrows][cap] {position, plane value}, ascending
 	uint32_t *misc;      // [0] state after the last D-1 bytes from the root
 	uint32_t *path_marker, *giveups;
-	uint32_t nt;                  // experiment: non-temporal text loads
 	unsigned long long *stamps;   // debugging aid (ACM_SIEVE_STAMPS): [wave][8] clock readings, or null
 	// output
 	int32_t *pat_plane, *off_plane;
 	uint32_t plane_capacity;
 };
+
+// Both kinds of list are far longer than what they usually hold (a few samples per tile, a few
+// hits per row), and a row per page would cost every writer and reader an address translation:
+// the first kHead entries of each list live side by side in a small dense array, the rest (rare)
+// in the list proper.
+constexpr uint32_t kSampleHead = 32;   // a check wave reads a tile's samples one per lane
+constexpr uint32_t kHitHead = 8;       // the emit kernel reads a row's first hits 64 bytes per thread: rows side by side
+__device__ __forceinline__ uint2 *hit_slot(const SieveArgs &a, uint32_t row, uint32_t idx)
+{
+	return idx < kHitHead ? a.lhead + (size_t)row * kHitHead + idx : a.lists + (size_t)row * a.cap + idx;
+}
+__device__ __forceinline__ uint2 *sample_slot(const SieveArgs &a, uint32_t tile, uint32_t idx)
+{
+	return idx < kSampleHead ? a.shead + (size_t)tile * kSampleHead + idx : a.samples + (size_t)tile * a.scap + idx;
+}
 
 struct __attribute__((packed)) Unaligned8 {
 	uint64_t v;
@@ -220,21 +236,21 @@ __device__ __forceinline__ uint32_t agree64(const uint8_t *p, const uint8_t *q)
 //   kKeep   the first pass of a round: up to four go to registers (h), all are counted (h.n)
 //   kCount  a follower with more than four: count those at positions >= floor (h.n), note
 //           the first and the last of them (h.e3, h.e0)
-//   kWrite  ... and write those to dst, ascending
+//   kWrite  ... and write those to the row's list from index 'at' on, ascending
 enum { kKeep = 0, kCount = 1, kWrite = 2 };
 struct Follow {
 	uint32_t extent1, node;
 	bool at_end;
 };
 
-__device__ __forceinline__ void final_node(LaneHits &h, uint32_t x, uint32_t value, bool take, int mode, uint32_t floor,
-    uint2 *dst)
+__device__ __forceinline__ void final_node(const SieveArgs &a, LaneHits &h, uint32_t x, uint32_t value, bool take,
+    int mode, uint32_t floor, uint32_t row, uint32_t at)
 {
 	if (mode == kKeep) {
 		note_hit(h, x, value, take);
 	} else if (take && x >= floor) {
 		if (mode == kWrite)
-			dst[h.n] = make_uint2(x, value);
+			*hit_slot(a, row, at + h.n) = make_uint2(x, value);
 		if (h.n == 0)
 			h.e3 = x;
 		h.e0 = x;
@@ -243,11 +259,11 @@ __device__ __forceinline__ void final_node(LaneHits &h, uint32_t x, uint32_t val
 }
 
 __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32_t node, uint32_t run, uint32_t x, int mode,
-    uint32_t floor, uint2 *dst)
+    uint32_t floor, uint32_t row, uint32_t at)
 {
 	Follow f;
 	if (node >= a.F)   // a pattern of exactly D bytes, or one that ends a longer suffix
-		final_node(h, x, (uint32_t)a.out[node], x >= a.drop_before, mode, floor, dst);
+		final_node(a, h, x, (uint32_t)a.out[node], x >= a.drop_before, mode, floor, row, at);
 	for (;;) {
 		if (x + 1 >= a.n)
 			break;
@@ -305,7 +321,7 @@ __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32
 			value = a.report_state ? v.w : v.z;
 		}
 		x++;
-		final_node(h, x, value, node >= a.F && x >= a.drop_before, mode, floor, dst);
+		final_node(a, h, x, value, node >= a.F && x >= a.drop_before, mode, floor, row, at);
 		if (leaf)
 			break;
 	}
@@ -315,27 +331,10 @@ __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32
 	return f;
 }
 
-// State of a tile while its samples are checked; one per wave of the workgroup, in LDS.
-struct Tile {
-	uint32_t carry;      // largest extent + 1 of the followers checked so far, this tile's or in front of it
-	uint32_t count;      // hits staged
-	uint32_t first, last;
-	uint32_t akey, anode;
-	uint32_t gave_up;
-	uint32_t pad;
-};
-
-__device__ __forceinline__ void write_summary(const SieveArgs &a, const Tile &t, uint32_t row)
-{
-	uint32_t *s = a.summary + (size_t)row * kSummaryWords;
-	*(uint4 *)s = make_uint4(t.carry, t.gave_up ? kGaveUp : t.count, t.first, t.last);
-	*(uint2 *)(s + 4) = make_uint2(t.akey, t.anode);
-}
-
 // What a checker wave keeps in LDS between its two stages: the followers stage 1 found,
 // in start order, until stage 2 has a full round of them.
 struct FollowerQueue {
-	uint32_t *start, *node_slot, *run;   // [kQ2Cap] each; node | tile slot << 24
+	uint32_t *start, *node, *run;   // [kQ2Cap] each
 	uint32_t count;
 };
 
@@ -345,8 +344,8 @@ struct FollowerQueue {
 // to the follower queue, the lanes' followers one behind the other, a lane's own in
 // descending offset = ascending start order.
 template <int W>
-__device__ __forceinline__ void stage1_round(const SieveArgs &a, FollowerQueue &fq, uint32_t p, uint32_t gram,
-    uint32_t slot, bool act, uint32_t lane)
+__device__ __forceinline__ void stage1_round(const SieveArgs &a, FollowerQueue &fq, uint32_t p, uint32_t gram, bool act,
+    uint32_t lane)
 {
 	// the 24 bytes around the sample: A = [p-8, p), B = [p, p+8), C = [p+8, p+16)
 	uint64_t A = 0, B = 0, C = 0;
@@ -427,7 +426,7 @@ __device__ __forceinline__ void stage1_round(const SieveArgs &a, FollowerQueue &
 	for (int o = W - 1; o >= 0; o--)
 		if ((vmask >> o) & 1u) {
 			fq.start[idx] = p - (uint32_t)o;
-			fq.node_slot[idx] = ent[o].w | (slot << 24);
+			fq.node[idx] = ent[o].w;
 			fq.run[idx] = ent[o].z >> 16;
 			idx++;
 		}
@@ -435,26 +434,41 @@ __device__ __forceinline__ void stage1_round(const SieveArgs &a, FollowerQueue &
 	__builtin_amdgcn_wave_barrier();
 }
 
-// Stage 2, one follower per lane (ascending starts; equal tile slots are neighbours): follow,
-// shadow across the lanes, append the surviving hits to their tiles' lists.
-__device__ __forceinline__ void stage2_round(const SieveArgs &a, Tile *tiles, uint32_t row0, uint32_t s, uint32_t node,
-    uint32_t run, uint32_t slot, bool act, uint32_t lane, uint32_t &dbg_levels)
+// What a checker wave has found so far: one row of the emit kernel's input (wave-uniform values).
+struct Row {
+	uint32_t carry;      // largest extent + 1 of the followers so far
+	uint32_t count;      // hits staged in the row's list
+	uint32_t first, last;
+	uint32_t akey, anode;
+	uint32_t gave_up;
+};
+
+__device__ __forceinline__ void write_summary(const SieveArgs &a, const Row &t, uint32_t row)
+{
+	uint32_t *s = a.summary + (size_t)row * kSummaryWords;
+	*(uint4 *)s = make_uint4(t.carry, t.gave_up ? kGaveUp : t.count, t.first, t.last);
+	*(uint2 *)(s + 4) = make_uint2(t.akey, t.anode);
+}
+
+// Stage 2, one follower per lane (ascending starts): follow, shadow across the lanes, append the
+// surviving hits to the row's list.
+__device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, uint32_t row, uint32_t s, uint32_t node,
+    uint32_t run, bool act, uint32_t lane, uint32_t &dbg_levels)
 {
 	LaneHits h;
-	uint32_t E = 0, akey = 0, anode = 0, M = 0, mine = 0, keep = 0, base = 0;
+	uint32_t E = 0, akey = 0, anode = 0, M = 0, mine = 0, keep = 0;
 	bool big = false;
-	uint2 *dst = nullptr;
 	// A lane whose follower enters more than four final nodes (nested patterns) goes through the
-	// loop three times: keep/count all, count what the shadow leaves, write that.  The others once.
+	// loop twice: keep/count all, then count what the shadow leaves; a third pass writes that.
 #pragma nounroll
-	for (int mode = kKeep; mode <= kWrite; mode++) {
+	for (int mode = kKeep; mode <= kCount; mode++) {
 		if (mode == kKeep || big) {
 			h.n = 0;
 			h.e0 = h.v0 = h.e1 = h.v1 = h.e2 = h.v2 = h.e3 = h.v3 = 0;
 			h.levels = 0;
 		}
 		if (act && (mode == kKeep || big)) {
-			const Follow f = follow(a, h, node, run, s + a.D - 1, mode, M, dst);
+			const Follow f = follow(a, h, node, run, s + a.D - 1, mode, M, 0, 0);
 			E = f.extent1;
 			if (f.at_end) {
 				akey = s + 2;
@@ -469,23 +483,26 @@ __device__ __forceinline__ void stage2_round(const SieveArgs &a, Tile *tiles, ui
 					lv = max(lv, __shfl_xor(lv, o, 64));
 				dbg_levels += lv;
 			}
-			// shadow: a follower keeps its hits behind the extents of the followers in front of it -- of
-			// its own tile in earlier rounds (the tile's carry) and of this round (all tiles)
-			const uint32_t incl = wave_incl_max(E, lane);
-			uint32_t excl = __shfl_up(incl, 1, 64);
-			if (lane == 0)
-				excl = 0;
-			M = max(act ? tiles[slot].carry : 0u, excl);
 			big = h.n > 4;
 			if (!__ballot(big))
 				break;
-		} else if (mode == kCount) {
-			mine = big ? h.n : 0u;   // the write pass needs every lane's place in its tile's list: below
-			break;
+			// the count pass needs the shadow bound: below
+		}
+		if (mode == kKeep) {
+			const uint32_t incl0 = wave_incl_max(E, lane);
+			uint32_t excl0 = __shfl_up(incl0, 1, 64);
+			M = max(t.carry, lane == 0 ? 0u : excl0);
+		} else {
+			mine = big ? h.n : 0u;
 		}
 	}
-	// (the loop above ends after kKeep when no lane is big, after kCount otherwise; the write pass of the
-	// big lanes follows once the places are known)
+	// shadow: a follower keeps its hits behind the extents of the followers in front of it -- of
+	// earlier rounds (the row's carry) and of this round
+	const uint32_t incl = wave_incl_max(E, lane);
+	uint32_t excl = __shfl_up(incl, 1, 64);
+	if (lane == 0)
+		excl = 0;
+	M = max(t.carry, excl);
 	if (!big) {
 		const uint32_t nh = min(h.n, 4u);   // slot 3 holds the oldest (smallest position) of four
 		if (nh > 3 && h.e3 >= M) keep |= 1u;
@@ -495,77 +512,48 @@ __device__ __forceinline__ void stage2_round(const SieveArgs &a, Tile *tiles, ui
 		mine = (uint32_t)__popc(keep);
 	}
 	uint32_t total;
-	base = wave_excl_sum(mine, lane, total);
+	const uint32_t base = wave_excl_sum(mine, lane, total);
 	const uint32_t he[4] = { h.e3, h.e2, h.e1, h.e0 }, hv[4] = { h.v3, h.v2, h.v1, h.v0 };
 	uint32_t firstpos, lastpos;
-	if (big) {   // kCount left the first and the last position in e3 and e0
+	if (big) {   // the count pass left the first and the last position in e3 and e0
 		firstpos = h.e3;
 		lastpos = h.e0;
 	} else {
 		firstpos = (keep & 1u) ? he[0] : (keep & 2u) ? he[1] : (keep & 4u) ? he[2] : he[3];
 		lastpos = (keep & 8u) ? he[3] : (keep & 4u) ? he[2] : (keep & 2u) ? he[1] : he[0];
 	}
-	const uint32_t incl = wave_incl_max(E, lane);
-	// one tile (a run of lanes with the same slot) at a time
-	unsigned long long rem = __ballot(act);
-	while (rem) {
-		const uint32_t fl = (uint32_t)__ffsll((long long)rem) - 1u;
-		const uint32_t scur = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)fl);
-		const bool mineseg = act && slot == scur;
-		const unsigned long long seg = __ballot(mineseg);
-		rem &= ~seg;
-		const uint32_t ll = 63u - (uint32_t)__clzll((long long)seg);
-		const uint32_t seg_base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)fl);
-		const uint32_t seg_total = (uint32_t)__builtin_amdgcn_readlane((int)(base + mine), (int)ll) - seg_base;
-		const uint32_t segE = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)ll);
-		Tile *t = tiles + scur;
-		const uint32_t cnt0 = t->count;
-		const bool room = cnt0 + seg_total <= a.cap;   // (always: a list holds a hit per position the tile can reach)
-		if (mineseg && mine && room) {
-			uint2 *to = a.lists + (size_t)(row0 + scur) * a.cap + cnt0 + (base - seg_base);
-			if (big) {
-				dst = to;   // written by the third pass below
-			} else {
+	if (total) {
+		if (t.count + total > a.cap) {   // (cannot happen: a list holds a hit per position the row can reach)
+			t.gave_up = 1;
+		} else {
+			const uint32_t at = t.count + base;
+			if (!big) {
 				uint32_t k = 0;
 #pragma unroll
 				for (uint32_t i = 0; i < 4; i++)
 					if (keep & (1u << i))
-						to[k++] = make_uint2(he[i], hv[i]);
+						*hit_slot(a, row, at + k++) = make_uint2(he[i], hv[i]);
 			}
-		}
-		const unsigned long long keepers = __ballot(mineseg && mine != 0);
-		const unsigned long long alive = __ballot(mineseg && akey != 0);
-		uint32_t fp = 0, lp = 0, ak = 0, an = 0;
-		if (keepers) {
-			fp = (uint32_t)__builtin_amdgcn_readlane((int)firstpos, (int)((uint32_t)__ffsll((long long)keepers) - 1u));
-			lp = (uint32_t)__builtin_amdgcn_readlane((int)lastpos, (int)(63u - (uint32_t)__clzll((long long)keepers)));
-		}
-		if (alive) {
-			const int al = (int)((uint32_t)__ffsll((long long)alive) - 1u);
-			ak = (uint32_t)__builtin_amdgcn_readlane((int)akey, al);
-			an = (uint32_t)__builtin_amdgcn_readlane((int)anode, al);
-		}
-		if (lane == fl) {
-			t->carry = max(t->carry, segE);
-			if (!room)
-				t->gave_up = 1;
-			if (room && keepers) {
-				if (cnt0 == 0)
-					t->first = fp;
-				t->last = lp;
-				t->count = cnt0 + seg_total;
+			if (__ballot(big && mine)) {   // third pass: the big lanes write what the shadow leaves them
+				h.n = 0;
+				if (big && mine)
+					(void)follow(a, h, node, run, s + a.D - 1, kWrite, M, row, at);
 			}
-			if (alive && !t->akey) {
-				t->akey = ak;
-				t->anode = an;
-			}
+			const unsigned long long keepers = __ballot(mine != 0);
+			const uint32_t fp = (uint32_t)__builtin_amdgcn_readlane((int)firstpos, (int)((uint32_t)__ffsll((long long)keepers) - 1u));
+			const uint32_t lp = (uint32_t)__builtin_amdgcn_readlane((int)lastpos, (int)(63u - (uint32_t)__clzll((long long)keepers)));
+			if (t.count == 0)
+				t.first = fp;
+			t.last = lp;
+			t.count += total;
 		}
-		__builtin_amdgcn_wave_barrier();
 	}
-	if (__ballot(big && dst != nullptr)) {   // third pass: the big lanes write what the shadow leaves them
-		h.n = 0;
-		if (big && dst != nullptr)
-			(void)follow(a, h, node, run, s + a.D - 1, kWrite, M, dst);
+	t.carry = max(t.carry, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+	const unsigned long long alive = __ballot(akey != 0);
+	if (alive && !t.akey) {
+		const int al = (int)((uint32_t)__ffsll((long long)alive) - 1u);
+		t.akey = (uint32_t)__builtin_amdgcn_readlane((int)akey, al);
+		t.anode = (uint32_t)__builtin_amdgcn_readlane((int)anode, al);
 	}
 }
 
@@ -579,8 +567,8 @@ __device__ void side_walks(const SieveArgs &a)
 			st = a.cold[((size_t)st << 8) | a.text[x]];
 		a.misc[0] = st;
 	}
-	Tile t;
-	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.pad = 0;
+	Row t;
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
 	uint32_t state = a.init_state, x = 0;   // x: next byte to consume
 	uint32_t run = 0;                        // known unary, non-final path ahead of 'state'
 	while (state != 0) {
@@ -613,7 +601,7 @@ __device__ void side_walks(const SieveArgs &a)
 				t.gave_up = 1;
 				break;
 			}
-			a.lists[t.count] = make_uint2(x, (uint32_t)a.out[state]);
+			*hit_slot(a, 0, t.count) = make_uint2(x, (uint32_t)a.out[state]);
 			if (t.count == 0)
 				t.first = x;
 			t.last = x;
@@ -624,131 +612,181 @@ __device__ void side_walks(const SieveArgs &a)
 	write_summary(a, t, 0);
 }
 
+// Text loads the compiler does not know of, with the waits placed by hand (a wait names the
+// register it is for, so nothing that reads the register is scheduled above it).  The compiler's
+// own bookkeeping cannot wait for one group of a sub-block at a time here: it merges what is
+// pending around the loop (stores of the previous sub-block, which complete out of order with
+// loads) and falls back to waiting for everything.  vmcnt(N) is safe with stores pending: of the
+// operations that must have completed for N to be reached, at most the stores are not loads.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load16_nt(v4u &dst, const v4u *p)
+{
+	asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void load4_nt(uint32_t &dst, const uint32_t *p)
+{
+	asm volatile("global_load_dword %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(v4u &x, uint32_t &y)
+{
+	asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+
 // ------------------------------------------------------------------- K1 ---
 // The bulk pass.  Persistent workgroups keep the Bloom filter in LDS; a wave owns a tile
 // at a time, reads it 16 bytes per lane, tests one 3-gram per W bytes and writes the
 // samples the filter flags -- position and 3-gram -- to the tile's list in position order
 // (ranks from ballots: no scan, no LDS queue).  Nothing here waits on a dependent load.
-template <int W>
+template <int W, bool DBG>
 __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	constexpr uint32_t S = 16 / W;                              // samples per 16-byte group
-	constexpr uint32_t LOADS = 8;                               // groups per lane per sub-block
+	constexpr uint32_t LOADS = W >= 4 ? 8 : W == 2 ? 4 : 2;     // groups per lane per sub-block: S * LOADS <= 32 flag bits
 	constexpr uint32_t SUB = LOADS * 1024;                      // bytes of a sub-block
+	constexpr uint32_t SMASK = (1u << S) - 1u;
 	const uint32_t nwaves = gridDim.x * kWaves;
 	const uint32_t n16 = a.n_pad >> 4;
 	const uint32_t *text32 = (const uint32_t *)a.text16;
 
-	uint4 w[LOADS];
+	v4u w[LOADS];
 	uint32_t nx[LOADS];
-	// the groups of the sub-block at 'off' of 'tile': issued early, probed later
+	uint32_t present = 0;   // bit j: group j of the sub-block exists for this lane
+	constexpr int PER = W <= 2 ? 2 : 1;   // load instructions per group
+	// the groups of the sub-block at 'off' of 'tile'.  Always exactly LOADS * PER load instructions,
+	// whatever exists of the tile (what does not exist is read at the start of the text and masked
+	// out): the waits count them.  Non-temporal: the text is read once, the tables the check kernel
+	// needs stay in L2.
 	auto issue = [&](uint32_t tile, uint32_t off) {
+		present = 0;
 #pragma unroll
 		for (uint32_t j = 0; j < LOADS; j++) {
 			const uint32_t rel = off + j * 1024;
 			const uint32_t g16 = ((tile * a.tile_bytes + rel) >> 4) + lane;   // wraps only for tiles that do not exist
 			const bool ok = tile < a.ntiles && rel < a.tile_bytes && g16 < n16;
-			if (!ok) {
-				w[j] = make_uint4(0, 0, 0, 0);
-			} else if (a.nt & 1) {
-				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-				const v4u v = __builtin_nontemporal_load((const v4u *)&a.text16[g16]);
-				w[j] = make_uint4(v.x, v.y, v.z, v.w);
-			} else {
-				w[j] = a.text16[g16];
-			}
+			present |= (ok ? 1u : 0u) << j;
+			load16_nt(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
 			if (W <= 2)
-				nx[j] = (ok && g16 + 1 < n16) ? text32[(size_t)g16 * 4 + 4] : 0u;
+				load4_nt(nx[j], text32 + (ok && g16 + 1 < n16 ? (size_t)g16 * 4 + 4 : 0));
+			else
+				nx[j] = 0;
 		}
 	};
+	// group j has arrived (and everything issued before it)
+	auto arrived = [&](uint32_t j) {
+		if (j == 0) wait_loads<(LOADS - 1) * PER>(w[0], nx[0]);
+		if (LOADS > 1 && j == 1) wait_loads<(LOADS > 1 ? LOADS - 2 : 0) * PER>(w[LOADS > 1 ? 1 : 0], nx[LOADS > 1 ? 1 : 0]);
+		if (LOADS > 2 && j == 2) wait_loads<(LOADS > 2 ? LOADS - 3 : 0) * PER>(w[LOADS > 2 ? 2 : 0], nx[LOADS > 2 ? 2 : 0]);
+		if (LOADS > 3 && j == 3) wait_loads<(LOADS > 3 ? LOADS - 4 : 0) * PER>(w[LOADS > 3 ? 3 : 0], nx[LOADS > 3 ? 3 : 0]);
+		if (LOADS > 4 && j == 4) wait_loads<(LOADS > 4 ? LOADS - 5 : 0) * PER>(w[LOADS > 4 ? 4 : 0], nx[LOADS > 4 ? 4 : 0]);
+		if (LOADS > 5 && j == 5) wait_loads<(LOADS > 5 ? LOADS - 6 : 0) * PER>(w[LOADS > 5 ? 5 : 0], nx[LOADS > 5 ? 5 : 0]);
+		if (LOADS > 6 && j == 6) wait_loads<(LOADS > 6 ? LOADS - 7 : 0) * PER>(w[LOADS > 6 ? 6 : 0], nx[LOADS > 6 ? 6 : 0]);
+		if (LOADS > 7 && j == 7) wait_loads<0>(w[LOADS > 7 ? 7 : 0], nx[LOADS > 7 ? 7 : 0]);
+	};
+	// the 3-gram of sample k of group j (registers)
+	auto gram_of = [&](uint32_t j, uint32_t k) -> uint32_t {
+		const uint32_t x[5] = { w[j].x, w[j].y, w[j].z, w[j].w, nx[j] };
+		const uint32_t b = k * W, i = b / 4, sh = b % 4;
+		const uint32_t v = sh == 0 ? x[i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i], sh);
+		return v & 0xFFFFFFu;
+	};
 	uint32_t tile = blockIdx.x * kWaves + wv, off = 0;
-	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x * kWaves + wv) * 8 : nullptr;
-	if (stamp && lane == 0)
+	unsigned long long *stamp = DBG && a.stamps ? a.stamps + (size_t)(blockIdx.x * kWaves + wv) * 8 : nullptr;
+	if (DBG && stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	{
-		// the filter first (it is needed first), then the text: both in flight before anything waits
-		constexpr uint32_t PER = (1u << acm::kSieveMaxLogWords) / 4 / kBlock;   // 16-byte pieces per thread, at most
-		const uint4 *src = (const uint4 *)a.bloom;
-		uint4 *dst = (uint4 *)bloom;
-		const uint32_t cnt = a.bloom_words / 4;
-		const uint32_t rot = (blockIdx.x * 61u) % cnt;   // the workgroups do not start on the same L2 channel
-		uint4 piece[PER];
-		uint32_t where[PER];
-#pragma unroll
-		for (uint32_t k = 0; k < PER; k++) {
-			const uint32_t i = threadIdx.x + k * kBlock;
-			uint32_t j = i + rot;
-			j = j >= cnt ? j - cnt : j;
-			where[k] = j;
-			piece[k] = src[i < cnt ? j : 0];   // always a load: a conditionally filled array would live in scratch
+		// The filter goes to LDS by DMA (no registers, nothing waits yet), 1 KiB pieces dealt over the
+		// waves; then the text loads; then a wait for the filter only -- the text keeps arriving
+		// while the first groups are probed.
+		const uint32_t pieces = a.bloom_words / 256;
+		const uint32_t rot = (blockIdx.x * 7u) % pieces;   // the workgroups do not start on the same L2 channel
+		for (uint32_t c = wv; c < pieces; c += kWaves) {
+			uint32_t piece = c + rot;
+			piece = piece >= pieces ? piece - pieces : piece;
+			// (inline asm, not the builtin: the compiler makes every LDS read after a DMA it knows of wait
+			// for ALL outstanding loads, the text included; the wait and the barrier below are what
+			// orders the filter's arrival before its first use)
+			const uint32_t lds_at = __builtin_amdgcn_readfirstlane(
+			    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(bloom + piece * 256));
+			const uint4 *from = (const uint4 *)a.bloom + piece * 64 + lane;
+			uint32_t keep_m0;
+			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+			    : "=&s"(keep_m0) : "s"(lds_at), "v"(from) : "memory");
 		}
 		issue(tile, off);
-#pragma unroll
-		for (uint32_t k = 0; k < PER; k++)
-			if (threadIdx.x + k * kBlock < cnt)
-				dst[where[k]] = piece[k];
+		asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * PER) : "memory");
 	}
-	__syncthreads();
-	if (stamp && lane == 0)
+	__builtin_amdgcn_s_barrier();   // (not __syncthreads: its fence would wait for the text as well)
+	if (DBG && stamp && lane == 0)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
 	const uint32_t word_shift = 32 - a.bloom_log_words;
 	const unsigned long long lt = (1ull << lane) - 1ull;   // the lanes in front of this one
 
 	uint32_t qn = 0;   // samples of the current tile written so far
+	bool first = true;
 	while (tile < a.ntiles) {
+		// A sub-block's loads are issued here and probed in order as they arrive (the first one's were
+		// issued above, in front of the filter's wait); the flagged samples are stored once all
+		// groups are probed.  Other waves of the CU cover the latency.
+		if (!first)
+			issue(tile, off);
+		first = false;
 		const uint32_t base = tile * a.tile_bytes + off;
-		uint2 *list = a.samples + (size_t)tile * a.scap;
+		uint32_t f = 0;
 #pragma unroll
 		for (uint32_t j = 0; j < LOADS; j++) {
-			const uint32_t x[5] = { w[j].x, w[j].y, w[j].z, w[j].w, W <= 2 ? nx[j] : 0u };
 			const uint32_t pos0 = base + j * 1024 + lane * 16;
-			// samples whose 3-gram lies inside the text (none for groups that were not loaded)
-			const bool loaded = off + j * 1024 < a.tile_bytes && pos0 + 2 < a.n;
+			// samples whose 3-gram lies inside the text (none for groups that do not exist)
+			const bool loaded = ((present >> j) & 1u) && pos0 + 2 < a.n;
 			const uint32_t room = loaded ? (a.n - 2 - pos0 + W - 1) / W : 0u;
-			uint32_t gram[S], fj = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < S; k++) {
-				const uint32_t b = k * W, i = b / 4, sh = b % 4;
-				const uint32_t v = sh == 0 ? x[i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i], sh);
-				gram[k] = v & 0xFFFFFFu;
-				fj |= (k < room ? bloom_hit(bloom, gram[k], word_shift) : 0u) << k;
-			}
-			if (!__ballot(fj != 0))
-				continue;
-			// rank of sample (lane, k) among the flagged ones of this group row, lane-major
-			uint32_t before = 0, all = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < S; k++) {
-				const unsigned long long bk = __ballot((fj >> k) & 1u);
-				before += (uint32_t)__popcll(bk & lt);
-				all += (uint32_t)__popcll(bk);
-			}
+			arrived(j);
+			uint32_t fj = 0;
 #pragma unroll
 			for (uint32_t k = 0; k < S; k++)
-				if ((fj >> k) & 1u) {
-					const uint32_t at = qn + before + (uint32_t)__popc(fj & ((1u << k) - 1u));
-					list[at] = make_uint2(pos0 + k * W, gram[k]);
-				}
-			qn += all;
+				fj |= (k < room ? bloom_hit(bloom, gram_of(j, k), word_shift) : 0u) << k;
+			f |= fj << (j * S);
 		}
-		if (stamp && lane == 0 && stamp[2] == 0)
+		if (DBG && stamp && lane == 0 && stamp[2] == 0)
 			stamp[2] = __builtin_amdgcn_s_memrealtime();
+		// the flagged samples go to the tile's list in position order: ranks from ballots
+		if (__ballot(f != 0)) {
+#pragma unroll
+			for (uint32_t j = 0; j < LOADS; j++) {
+				const uint32_t fj = (f >> (j * S)) & SMASK;
+				if (!__ballot(fj != 0))
+					continue;
+				const uint32_t pos0 = base + j * 1024 + lane * 16;
+				uint32_t before = 0, all = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < S; k++) {
+					const unsigned long long bk = __ballot((fj >> k) & 1u);
+					before += (uint32_t)__popcll(bk & lt);
+					all += (uint32_t)__popcll(bk);
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < S; k++)
+					if ((fj >> k) & 1u) {
+						const uint32_t at = qn + before + (uint32_t)__popc(fj & ((1u << k) - 1u));
+						*sample_slot(a, tile, at) = make_uint2(pos0 + k * W, gram_of(j, k));
+					}
+				qn += all;
+			}
+		}
 		const uint32_t cur = tile;
 		off += SUB;
 		if (off >= a.tile_bytes) {
 			off = 0;
 			tile += nwaves;
 		}
-		issue(tile, off);   // the next sub-block's loads fly while this one's flags are written
 		if (tile != cur) {
 			if (lane == 0)
 				a.scount[cur] = qn;
 			qn = 0;
 		}
 	}
-	if (stamp && lane == 0)
+	if (DBG && stamp && lane == 0)
 		stamp[4] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -761,28 +799,25 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 template <int W>
 __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
 {
-	__shared__ uint32_t q2[kCheckBlock / 64][3][kQ2Cap];
-	__shared__ Tile tstate[kCheckBlock / 64][kTilesPerChecker];
-	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	__shared__ uint32_t q2[3][kQ2Cap];
+	const uint32_t lane = threadIdx.x;
 	if (blockIdx.x == gridDim.x - 1) {
 		if (threadIdx.x == 0)
 			side_walks(a);
 		return;
 	}
-	const uint32_t tile0 = (blockIdx.x * (kCheckBlock / 64) + wv) * kTilesPerChecker;
-	if (tile0 >= a.ntiles)
-		return;
-	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x * (kCheckBlock / 64) + wv + 8192) * 8 : nullptr;
+	const uint32_t tile0 = blockIdx.x * kTilesPerChecker;
+	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x + 8192) * 8 : nullptr;
 	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
 	if (stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
-	Tile *tiles = tstate[wv];
-	if (lane < kTilesPerChecker * (sizeof(Tile) / 4))
-		((uint32_t *)tiles)[lane] = 0;
+	Row t;
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
+	const uint32_t row = blockIdx.x + 1;   // row 0 is the carried-state walker's
 	FollowerQueue fq;
-	fq.start = q2[wv][0];
-	fq.node_slot = q2[wv][1];
-	fq.run = q2[wv][2];
+	fq.start = q2[0];
+	fq.node = q2[1];
+	fq.run = q2[2];
 	fq.count = 0;
 	// the lists of this wave's tiles, one behind the other
 	uint32_t mycount = 0;
@@ -794,36 +829,35 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
 	for (uint32_t k = 0; k < kTilesPerChecker; k++)
 		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)k);
 	const uint32_t nsamples = cum[kTilesPerChecker];
-	__builtin_amdgcn_wave_barrier();
 	uint32_t r0 = 0;
 	for (;;) {
 		if (fq.count >= 64 || (r0 >= nsamples && fq.count > 0)) {   // stage 2: a round of followers
 			const uint32_t cnt = min(fq.count, 64u);
 			const bool act = lane < cnt;
-			const uint32_t s0 = act ? fq.start[lane] : 0u, ns = act ? fq.node_slot[lane] : 0u;
+			const uint32_t s0 = act ? fq.start[lane] : 0u, nd = act ? fq.node[lane] : 0u;
 			const uint32_t rn = act ? fq.run[lane] : 0u;
 			// what is left moves to the front of the queue
 			const uint32_t left = fq.count - cnt;
 			uint32_t m0 = 0, m1 = 0, m2 = 0;
 			if (lane < left) {
 				m0 = fq.start[cnt + lane];
-				m1 = fq.node_slot[cnt + lane];
+				m1 = fq.node[cnt + lane];
 				m2 = fq.run[cnt + lane];
 			}
 			__builtin_amdgcn_wave_barrier();
 			if (lane < left) {
 				fq.start[lane] = m0;
-				fq.node_slot[lane] = m1;
+				fq.node[lane] = m1;
 				fq.run[lane] = m2;
 			}
 			for (uint32_t i = 64 + lane; i < left; i += 64) {   // more than 64 left: ascending copy is safe (i < cnt + i)
 				fq.start[i] = fq.start[cnt + i];
-				fq.node_slot[i] = fq.node_slot[cnt + i];
+				fq.node[i] = fq.node[cnt + i];
 				fq.run[i] = fq.run[cnt + i];
 				__builtin_amdgcn_wave_barrier();
 			}
 			fq.count = left;
-			stage2_round(a, tiles, tile0 + 1, s0, ns & 0xFFFFFFu, rn, ns >> 24, act, lane, dbg_levels);
+			stage2_round(a, t, row, s0, nd, rn, act, lane, dbg_levels);
 			continue;
 		}
 		if (r0 >= nsamples)
@@ -838,14 +872,14 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
 		}
 		uint2 it = make_uint2(0, 0);
 		if (act)
-			it = a.samples[(size_t)(tile0 + slot) * a.scap + (idx - before)];
+			it = *sample_slot(a, tile0 + slot, idx - before);
 		dbg_rounds++;
 		dbg_cands += min(nsamples - r0, 64u);
 		r0 += 64;
-		stage1_round<W>(a, fq, it.x, it.y, slot, act, lane);
+		stage1_round<W>(a, fq, it.x, it.y, act, lane);
 	}
-	if (lane < kTilesPerChecker && tile0 + lane < a.ntiles)   // the summaries of this wave's tiles
-		write_summary(a, tiles[lane], tile0 + lane + 1);
+	if (lane == 0)
+		write_summary(a, t, blockIdx.x + 1);
 	if (stamp && lane == 0) {
 		stamp[4] = __builtin_amdgcn_s_memrealtime();
 		stamp[5] = ((unsigned long long)dbg_rounds << 32) | dbg_cands;
@@ -883,16 +917,28 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 	return IS_MAX ? max(before, excl) : before + excl;
 }
 
-// Every workgroup works out the whole prefix (a few thousand 32-byte summaries, L2
-// resident) and copies its share of the records.
+// ------------------------------------------------------------------- K3 ---
+// Every workgroup works out the whole prefix (a thousand 32-byte summaries, L2 resident:
+// exclusive prefix max of the extents, exclusive prefix sum of what the shadow leaves of each
+// list) and copies its share of the records: a thread per output cell finds the cell's row by
+// binary search in LDS and moves one record, so that the stores of a wave lie side by side.  (The
+// owner of a row copying the row's records itself, one predicated store per possible record,
+// took three times as long: it is the instruction count of 1024 threads that matters here.)
 __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 {
 	__shared__ uint32_t lds[kEmitBlock / 64];
-	__shared__ uint32_t s_base[kMaxTiles + 2];   // first output cell of each row
-	__shared__ uint32_t s_drop[kMaxTiles + 1];   // shadowed head of each row's list
+	__shared__ uint32_t s_base[kMaxRows + 1];   // first output cell of each row
+	__shared__ uint32_t s_drop[kMaxRows];       // shadowed head of each row's list
 	__shared__ unsigned long long s_alive;
-	const uint32_t rows = a.ntiles + 1;
+	const uint32_t rows = a.nrows;
 	const uint32_t r0 = threadIdx.x * kRowsPerThread;
+	unsigned long long *stamp = a.stamps && threadIdx.x == 0 ? a.stamps + (size_t)(9000 + blockIdx.x) * 8 : nullptr;
+	if (stamp)
+		stamp[0] = __builtin_amdgcn_s_memrealtime();
+	// every kernel argument the kernel will need, fetched now, together (the compiler would fetch each
+	// where it is first used: a fetch from the argument buffer in front of every phase)
+	asm volatile("" :: "s"(a.pat_plane), "s"(a.off_plane), "s"(a.plane_capacity), "s"(a.off_shift), "s"(a.lhead),
+	    "s"(a.lists), "s"(a.cap), "s"(a.misc), "s"(a.dev2ref), "s"(a.path_marker), "s"(a.giveups), "s"(a.n));
 	if (threadIdx.x == 0)
 		s_alive = ~0ull;
 	uint32_t E[kRowsPerThread], cnt[kRowsPerThread], first[kRowsPerThread], last[kRowsPerThread];
@@ -901,12 +947,12 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 	unsigned long long alive = ~0ull;
 #pragma unroll
 	for (uint32_t i = 0; i < kRowsPerThread; i++) {
-		const uint32_t r = r0 + i;
-		uint4 s = make_uint4(0, 0, 0, 0);
-		uint2 al = make_uint2(0, 0);
-		if (r < rows) {
-			s = *(const uint4 *)(a.summary + (size_t)r * kSummaryWords);
-			al = *(const uint2 *)(a.summary + (size_t)r * kSummaryWords + 4);
+		const uint32_t r = r0 + i, rc = min(r, rows - 1);   // (loads without a branch around them: in flight together)
+		uint4 s = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords);
+		uint2 al = *(const uint2 *)(a.summary + (size_t)rc * kSummaryWords + 4);
+		if (r >= rows) {
+			s = make_uint4(0, 0, 0, 0);
+			al = make_uint2(0, 0);
 		}
 		E[i] = s.x;
 		cnt[i] = s.y;
@@ -926,6 +972,8 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 	}
 	if (alive != ~0ull)
 		atomicMin(&s_alive, alive);
+	if (stamp)
+		stamp[1] = __builtin_amdgcn_s_memrealtime();
 	uint32_t all_max, all_cells;
 	uint32_t carry = block_exclusive<true>(tmax, lds, &all_max);
 	uint32_t drop[kRowsPerThread], kept_sum = 0;
@@ -936,8 +984,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 			if (last[i] < carry) {
 				d = cnt[i];
 			} else {
-				const uint2 *list = a.lists + (size_t)(r0 + i) * a.cap;
-				while (d < cnt[i] && list[d].x < carry)
+				while (d < cnt[i] && hit_slot(a, r0 + i, d)->x < carry)
 					d++;
 			}
 		}
@@ -946,34 +993,40 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 		carry = max(carry, E[i]);
 	}
 	uint32_t cell = block_exclusive<false>(kept_sum, lds, &all_cells);
+	if (stamp)
+		stamp[2] = __builtin_amdgcn_s_memrealtime();
+	{
 #pragma unroll
-	for (uint32_t i = 0; i < kRowsPerThread; i++) {
-		const uint32_t r = r0 + i;
-		if (r < rows) {
-			s_base[r] = cell;
-			s_drop[r] = drop[i];
-			cell += cnt[i] - drop[i];
+		for (uint32_t i = 0; i < kRowsPerThread; i++) {
+			const uint32_t r = r0 + i;
+			if (r < rows) {
+				s_base[r] = cell;
+				s_drop[r] = drop[i];
+				cell += cnt[i] - drop[i];
+			}
+		}
+		if (threadIdx.x == 0)
+			s_base[rows] = all_cells;
+		__syncthreads();
+		// one thread per output cell: find the row it belongs to, copy the record
+		for (uint32_t c = blockIdx.x * kEmitBlock + threadIdx.x; c < all_cells; c += gridDim.x * kEmitBlock) {
+			uint32_t lo = 0, hi = rows;   // the row r with s_base[r] <= c < s_base[r + 1]
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_base[mid] <= c)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			const uint2 rec = *hit_slot(a, lo, s_drop[lo] + (c - s_base[lo]));
+			if (c + 2 < a.plane_capacity) {
+				a.pat_plane[1 + c] = (int32_t)rec.y;
+				a.off_plane[1 + c] = (int32_t)rec.x + a.off_shift;
+			}
 		}
 	}
-	if (threadIdx.x == 0)
-		s_base[rows] = all_cells;
-	__syncthreads();
-	// one thread per output cell: find the row it belongs to, copy the record
-	for (uint32_t c = blockIdx.x * kEmitBlock + threadIdx.x; c < all_cells; c += gridDim.x * kEmitBlock) {
-		uint32_t lo = 0, hi = rows;   // the row r with s_base[r] <= c < s_base[r + 1]
-		while (hi - lo > 1) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (s_base[mid] <= c)
-				lo = mid;
-			else
-				hi = mid;
-		}
-		const uint2 rec = a.lists[(size_t)lo * a.cap + s_drop[lo] + (c - s_base[lo])];
-		if (c + 2 < a.plane_capacity) {
-			a.pat_plane[1 + c] = (int32_t)rec.y;
-			a.off_plane[1 + c] = (int32_t)rec.x + a.off_shift;
-		}
-	}
+	if (stamp)
+		stamp[3] = __builtin_amdgcn_s_memrealtime();
 	if (blockIdx.x == 0 && threadIdx.x == 0) {   // header and trailer cells
 		const unsigned long long k = s_alive;
 		const uint32_t last_dev = k != ~0ull ? (uint32_t)k : a.misc[0];
@@ -990,16 +1043,19 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 		if (a.giveups && all_cells > a.n / kDenseDivisor)
 			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
+	if (stamp)
+		stamp[4] = __builtin_amdgcn_s_memrealtime();
 }
 
 size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
 
 struct Geometry {
-	uint32_t tile_bytes, ntiles, cap, scap;
+	uint32_t tile_bytes, ntiles, cap, scap, nrows;
 };
 
-// Nothing overflows: a tile's sample list has room for every sample of the tile, its hit list for
-// one hit per text position the tile's followers can reach (the shadow rule leaves at most one).
+// Nothing overflows: a tile's sample list has room for every sample of the tile, a row's hit list
+// for one hit per text position the followers of its tiles can reach (the shadow rule leaves at
+// most one per position).
 Geometry geometry_for(const acm_dfa *d, size_t n)
 {
 	Geometry g;
@@ -1007,7 +1063,8 @@ Geometry geometry_for(const acm_dfa *d, size_t n)
 	while ((n + g.tile_bytes - 1) / g.tile_bytes > kMaxTiles)
 		g.tile_bytes *= 2;
 	g.ntiles = (uint32_t)((n + g.tile_bytes - 1) / g.tile_bytes);
-	g.cap = g.tile_bytes + d->max_pattern_len + 8;
+	g.nrows = (g.ntiles + kTilesPerChecker - 1) / kTilesPerChecker + 1;
+	g.cap = kTilesPerChecker * g.tile_bytes + d->max_pattern_len + 8;
 	g.scap = g.tile_bytes / (d->sv_stride ? d->sv_stride : 1);
 	return g;
 }
@@ -1022,9 +1079,11 @@ size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
 		return 0;
 	const Geometry g = geometry_for(d, max_text);   // tile size and cap grow with the text, the tile count is bounded
 	size_t o = 0;
-	o += align_up((size_t)(kMaxTiles + 1) * kSummaryWords * 4, 256);
-	o += align_up((size_t)(g.ntiles + 1) * g.cap * 8, 256);
+	o += align_up((size_t)kMaxRows * kSummaryWords * 4, 256);
+	o += align_up((size_t)g.nrows * g.cap * 8, 256);
 	o += align_up((size_t)g.ntiles * g.scap * 8 + 64, 256);
+	o += align_up((size_t)kMaxTiles * kSampleHead * 8, 256);
+	o += align_up((size_t)(kMaxRows + kRowsPerThread) * kHitHead * 8, 256);
 	o += align_up((size_t)kMaxTiles * 4, 256);
 	o += 256;
 	return o;
@@ -1033,10 +1092,11 @@ size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
 int sparse_prepare(const acm_dfa *)
 {
 	const int lds = (int)((1u << acm::kSieveMaxLogWords) * 4);
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_sieve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+	const void *kernels[] = { (const void *)k_sieve<8, false>, (const void *)k_sieve<4, false>, (const void *)k_sieve<2, false>,
+		(const void *)k_sieve<1, false>, (const void *)k_sieve<8, true>, (const void *)k_sieve<4, true>,
+		(const void *)k_sieve<2, true>, (const void *)k_sieve<1, true> };
+	for (const void *k : kernels)
+		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 	return ACM_OK;
 }
 
@@ -1083,9 +1143,12 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		o += align_up(bytes, 256);
 		return p;
 	};
-	a.summary = (uint32_t *)take((size_t)(kMaxTiles + 1) * kSummaryWords * 4);
-	a.lists = (uint2 *)take((size_t)(g.ntiles + 1) * g.cap * 8);
+	a.summary = (uint32_t *)take((size_t)kMaxRows * kSummaryWords * 4);
+	a.lists = (uint2 *)take((size_t)g.nrows * g.cap * 8);
+	a.nrows = g.nrows;
 	a.samples = (uint2 *)take((size_t)g.ntiles * g.scap * 8);
+	a.shead = (uint2 *)take((size_t)g.ntiles * kSampleHead * 8);
+	a.lhead = (uint2 *)take((size_t)(g.nrows + kRowsPerThread) * kHitHead * 8);
 	a.scount = (uint32_t *)take((size_t)g.ntiles * 4);
 	a.scap = g.scap;
 	a.misc = (uint32_t *)take(256);
@@ -1096,8 +1159,7 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	a.giveups = d->d_giveups;
 	static unsigned long long *d_stamps = nullptr;
 	const bool want_stamps = getenv("ACM_SIEVE_STAMPS") != nullptr;
-	a.nt = getenv("ACM_SIEVE_NT") ? (uint32_t)atoi(getenv("ACM_SIEVE_NT")) : 1;   // non-temporal text loads: the tables stay in L2
-	const size_t stamp_words = (size_t)(8192 + 1024) * 8;
+	const size_t stamp_words = (size_t)(9000 + 128) * 8;
 	if (want_stamps) {
 		if (!d_stamps)
 			ACM_HIP_TRY(hipMalloc((void **)&d_stamps, stamp_words * 8));
@@ -1105,21 +1167,35 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		a.stamps = d_stamps;
 	}
 
-	// K1: persistent workgroups of 16 waves, a tile per wave at a time; a small filter leaves room
-	// for two workgroups per CU
-	const size_t lds = (size_t)a.bloom_words * 4;
-	const uint32_t per_cu = lds <= 72 * 1024 ? 2 : 1;
+	// K1: persistent workgroups of 16 waves, a tile per wave at a time, ONE workgroup per CU (it asks
+	// for more than half of the LDS whatever the filter's size): 16 waves with 8 KiB in flight each
+	// saturate the memory system, and the other half of the CU's wave slots stays free for the check
+	// and emit kernels of the batches in flight on other streams -- with two bulk kernels resident
+	// everywhere those would wait for a whole bulk workgroup to drain, every time.
+	const size_t lds = std::max((size_t)a.bloom_words * 4, (size_t)84 * 1024);
 	uint32_t blocks = (g.ntiles + kWaves - 1) / kWaves;
-	if (blocks > (uint32_t)d->num_cus * per_cu)
-		blocks = (uint32_t)d->num_cus * per_cu;
+	if (blocks > (uint32_t)d->num_cus)
+		blocks = (uint32_t)d->num_cus;
 	// K2: a wave per kTilesPerChecker tiles, and one workgroup for the serial walks
-	const uint32_t cwaves = (g.ntiles + kTilesPerChecker - 1) / kTilesPerChecker;
-	const uint32_t cblocks = (cwaves + kCheckBlock / 64 - 1) / (kCheckBlock / 64) + 1;
-	switch (d->sv_stride) {
-	case 8: hipLaunchKernelGGL(k_sieve<8>, dim3(blocks), dim3(kBlock), lds, s, a); break;
-	case 4: hipLaunchKernelGGL(k_sieve<4>, dim3(blocks), dim3(kBlock), lds, s, a); break;
-	case 2: hipLaunchKernelGGL(k_sieve<2>, dim3(blocks), dim3(kBlock), lds, s, a); break;
-	default: hipLaunchKernelGGL(k_sieve<1>, dim3(blocks), dim3(kBlock), lds, s, a); break;
+	const uint32_t cwaves = g.nrows - 1;
+	const uint32_t cblocks = cwaves + 1;
+	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
+	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)
+		eblocks *= 2;
+	if (!want_stamps) {
+		switch (d->sv_stride) {
+		case 8: hipLaunchKernelGGL((k_sieve<8, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 4: hipLaunchKernelGGL((k_sieve<4, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		default: hipLaunchKernelGGL((k_sieve<1, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		}
+	} else {   // debugging aid: the same kernel with clock stamps
+		switch (d->sv_stride) {
+		case 8: hipLaunchKernelGGL((k_sieve<8, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 4: hipLaunchKernelGGL((k_sieve<4, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		default: hipLaunchKernelGGL((k_sieve<1, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		}
 	}
 	if (after_sieve)
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
@@ -1129,8 +1205,6 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
 	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
 	}
-	uint32_t eblocks = (uint32_t)(n >> 22);
-	eblocks = eblocks < 4 ? 4 : eblocks > 64 ? 64 : eblocks;
 	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks), dim3(kEmitBlock), 0, s, a);
 	if (after_emit)
 		ACM_HIP_TRY(hipEventRecord(after_emit, s));
@@ -1169,6 +1243,10 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		const char *n2[5] = { "start", "", "", "", "end" };
 		report("sieve", 0, (size_t)blocks * kWaves, n1);
 		report("check", 8192, cwaves, n2);
+		const char *n3[5] = { "start", "loaded", "scanned", "copied", "end" };
+		report("emit", 9000, eblocks, n3);
+		for (uint32_t bl = 0; bl < eblocks; bl++)
+			(void)bl;
 		{
 			std::vector<double> by[40];
 			for (size_t i = 8192; i < 8192 + cwaves; i++) {

@@ -189,6 +189,9 @@ typedef struct acm_scan_batch {
 	void *wait_before_walk;		/* hipEvent_t or NULL */
 	void *record_after_walk;	/* hipEvent_t or NULL */
 	int report;			/* ACM_REPORT_* */
+	int profile;			/* non-zero: time this batch's kernels with
+					 * events as acm_scan_profile_enable does
+					 * for all (acm_scan_profile_read collects) */
 } acm_scan_batch;
 
 /* What the pattern plane of a scan holds per record.
@@ -257,7 +260,9 @@ int acm_scan_path_taken(const acm_dfa *, const void *d_workspace, size_t n, void
  * (sparse: the candidate walk; chain: none, 0 ms) and after its last.
  * acm_scan_profile_read waits for the recorded events, returns the summed
  * milliseconds of the first kernel, the second, and the whole pipeline over
- * 'launches' calls, and resets the accumulation. */
+ * 'launches' calls, and resets the accumulation.  (Sparse pipeline: first =
+ * the bulk kernel k_sieve, second = check + emit.)  Safe to use while other
+ * threads enqueue scans on other streams. */
 int acm_scan_profile_enable(acm_dfa *, int enable);
 int acm_scan_profile_read(acm_dfa *, double *first_ms, double *second_ms,
     double *pipeline_ms, int *launches);
@@ -287,17 +292,21 @@ int acm_bitonic_sort_u32(uint32_t *d_key_dst, uint32_t *d_val_dst,
 
 /* compact planes (position ordered) -> the reference's bucket planes
  * results/results2 [max_results][chunks] + trailer (ahomatch.cl:63-75,
- * :90-93, :160-162 layout; databuf.c:747-782 reads it) */
+ * :90-93, :160-162 layout; databuf.c:747-782 reads it).  plane_capacity =
+ * cells of the compact planes: a plane whose count exceeds plane_capacity - 2
+ * holds the first plane_capacity - 2 records and its trailer in the last cell. */
 int acm_bucketize(const int32_t *d_pat_plane, const int32_t *d_off_plane,
     const int32_t *d_indices, const int32_t *d_sizes, int chunks,
-    int max_results, int32_t *d_results, int32_t *d_results2, void *stream);
+    int max_results, int32_t *d_results, int32_t *d_results2,
+    size_t plane_capacity, void *stream);
 
 /* chunk list -> contiguous stream and back.  The reference scans chunk by
  * chunk (indices[]/sizes[], databuf.c:326-481) and chunks may be separated by
  * zero padding; acm_pack_chunks copies chunk i to d_dst + d_packed_start[i],
  * acm_remap_offsets rewrites the offsets of a compact plane (scanned over the
  * packed stream) into offsets of the original buffer.  max_records bounds
- * the launch; the record count is read from d_off_plane[0] on the device. */
+ * the launch and the records touched (at most plane capacity - 2); the
+ * record count is read from d_off_plane[0] on the device. */
 int acm_pack_chunks(void *d_dst, const void *d_src, const int32_t *d_indices,
     const int32_t *d_sizes, const int32_t *d_packed_start, int chunks,
     void *stream);

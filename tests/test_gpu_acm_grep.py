@@ -128,6 +128,36 @@ def test_all_patterns_flag(gpu, tmp_path):
     o.close()
 
 
+def test_all_patterns_on_nested_patterns(gpu, tmp_path):
+    """-A where patterns nest (aaa, aaaa, aaaaa over a run of a's): more records than text bytes.
+    Up to four per byte the expanded planes hold them all; beyond that acm_grep stops with an
+    error instead of reading past its planes."""
+    text = np.full(20000, ord("a"), dtype=np.uint8)
+    text[::997] = ord("b")
+    text_path = tmp_path / "in.txt"
+    text.tofile(str(text_path))
+    for npat, fits in ((3, True), (16, False)):      # (-G is rounded up to 16 chunks: the planes hold 4 x 64 Ki records)
+        words = [b"a" * (3 + k) for k in range(npat)]
+        pat_path = tmp_path / ("pats%d.txt" % npat)
+        pat_path.write_bytes(b"\n".join(words) + b"\n")
+        args = ["-f", str(text_path), "-p", str(pat_path), "-B", "4096", "-D", "0", "-G", "8", "-L", "1024",
+                "-R", "16384", "-w", "1", "-v", "-A"]
+        if fits:
+            o = orc.Oracle()
+            o.load(str(pat_path))
+            o.compile()
+            all_pos, all_pat, _ = o.scan_all(text)
+            assert all_pos.size > 2 * text.size
+            hits, stats, _ = run(CLI, args)
+            assert int(stats["Matches"]) == all_pos.size
+            got = [(int(h[3]) - 1, h[1]) for h in hits]
+            assert got == [(int(p), o.pattern(int(k))[0].decode()) for p, k in zip(all_pos, all_pat)]
+            o.close()
+        else:
+            p = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=180, errors="replace")
+            assert p.returncode == 1 and "-A produced" in p.stderr
+
+
 def test_follow_mode_sees_appended_data(gpu, tmp_path):
     """-F (ocl_aho_grep.c:96-99): the worker keeps polling its files; data appended later is scanned
     from the state the earlier data left (a signature cut by the append boundary is found), and
