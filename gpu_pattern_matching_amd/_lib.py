@@ -27,6 +27,12 @@ class ScanBatch(C.Structure):
                 ("profile", C.c_int)]
 
 
+class ShardPlan(C.Structure):
+    """struct acm_shard_plan (include/acmatch.h)."""
+    _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("halo", C.c_size_t), ("load_begin", C.c_size_t),
+                ("load_bytes", C.c_size_t), ("offset_shift", C.c_long)]
+
+
 REPORT_HEAD, REPORT_STATE = 0, 1
 
 
@@ -86,6 +92,9 @@ NATIVE_API = {
     "acm_bucketize": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "acm_pack_chunks": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "acm_remap_offsets": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),
+    "acm_shard_plan_for": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
+    "acm_gather_planes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "acm_merge_planes": (C.c_long, [_vp, _vp, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "acm_rt_set_device": (C.c_int, [C.c_int]),
     "acm_rt_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "acm_rt_free": (C.c_int, [_vp]),

@@ -17,7 +17,7 @@ OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libacmatch.so")
 CLI = os.path.join(PKG, "acm_grep")          # native CLI (csrc/acm_grep.cpp), host code only
 
-SOURCES = ["automaton.cpp", "device_dfa.hip", "scan.hip", "sparse.hip", "post.hip", "runtime.hip", "compat.hip"]
+SOURCES = ["automaton.cpp", "multi.cpp", "device_dfa.hip", "scan.hip", "sparse.hip", "post.hip", "runtime.hip", "compat.hip"]
 ARCH = "gfx950"
 
 
@@ -64,7 +64,7 @@ def build(force=False, keep_temps=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=OBJ)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

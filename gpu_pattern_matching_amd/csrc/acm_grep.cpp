@@ -60,7 +60,8 @@ double now_us()
 	       "  -p file        patterns, one per line (plain, \"quoted\", or 'ID pattern')\n"
 	       "  -F             keep processing data appended to the inputs (e.g. a FIFO)\n"
 	       "  -B chunk_size  chunk size in bytes (result buckets are per chunk)\n"
-	       "  -D devpos      HIP device ordinal\n"
+	       "  -D devpos      HIP device ordinal, or a list (0,1,2,...): worker i runs on entry i mod\n"
+	       "                 the list length, each device holds its own copy of the automaton\n"
 	       "  -G global_ws   chunks per buffer: buffer = global_ws * chunk_size bytes\n"
 	       "  -L local_ws    accepted for compatibility; the launch shape is the library's\n"
 	       "  -m max         use at most max bytes of every pattern\n"
@@ -112,13 +113,14 @@ std::vector<std::string> regular_files_in(std::string dir)
 struct Config {
 	std::string pat_path, data_path;
 	int dev = -1, hex = 0, verbose = 0, text_mode = 0, follow = 0, threads = 2, all_patterns = 0;
+	std::vector<int> devs;   // -D 0,1,...: worker i runs on devs[i % devs.size()] (the reference has one -D)
 	int max_results = MAX_RESULTS, pat_limit = -1;
 	long global_ws = -1, local_ws = -1, chunk = -1;
 };
 
 struct Shared {
 	Config cfg;
-	acm_dfa *dfa = nullptr;
+	std::vector<acm_dfa *> dfas;   // one per entry of cfg.devs
 	std::vector<std::string> files;
 	std::vector<int> fds;
 	std::vector<std::string> pat_bytes;   // for the -v line
@@ -146,6 +148,8 @@ struct Buffer {   // one of the two staging buffers of a worker
 };
 
 struct Worker {
+	acm_dfa *dfa = nullptr;   // the copy on this worker's device
+	int dev = 0;
 	Shared *sh = nullptr;
 	int id = 0;
 	pthread_t thread{};
@@ -276,7 +280,7 @@ void submit(Worker &w, Buffer &b)
 	}
 	int32_t *pat = (int32_t *)b.d_pat, *off = (int32_t *)b.d_off;
 	if (!c.all_patterns) {
-		CK(acm_scan_async(w.sh->dfa, text, stream_len, w.last_state, w.ws, w.ws_bytes, pat, off, cap, s));
+		CK(acm_scan_async(w.dfa, text, stream_len, w.last_state, w.ws, w.ws_bytes, pat, off, cap, s));
 	} else {   // final states instead of head patterns, then every pattern of each state's match list
 		acm_scan_batch sb;
 		memset(&sb, 0, sizeof(sb));
@@ -290,8 +294,8 @@ void submit(Worker &w, Buffer &b)
 		sb.plane_capacity = cap;
 		sb.stream = s;
 		sb.report = ACM_REPORT_STATE;
-		CK(acm_scan_batch_async(w.sh->dfa, &sb));
-		CK(acm_expand_matches_async(w.sh->dfa, pat, off, cap - 2, (int32_t *)b.d_pat_all, (int32_t *)b.d_off_all,
+		CK(acm_scan_batch_async(w.dfa, &sb));
+		CK(acm_expand_matches_async(w.dfa, pat, off, cap - 2, (int32_t *)b.d_pat_all, (int32_t *)b.d_off_all,
 		    b.all_cap, b.d_expand_ws, b.expand_ws_bytes, s));
 		pat = (int32_t *)b.d_pat_all;
 		off = (int32_t *)b.d_off_all;
@@ -360,9 +364,9 @@ void *worker_main(void *arg)
 	Worker &w = *(Worker *)arg;
 	Shared &sh = *w.sh;
 	const Config &c = sh.cfg;
-	CK(acm_rt_set_device(c.dev));
+	CK(acm_rt_set_device(w.dev));
 	CK(acm_rt_stream_create(&w.stream));
-	w.ws_bytes = acm_scan_workspace_bytes(sh.dfa, (size_t)c.global_ws * c.chunk);
+	w.ws_bytes = acm_scan_workspace_bytes(w.dfa, (size_t)c.global_ws * c.chunk);
 	CK(acm_rt_malloc(&w.ws, w.ws_bytes));
 	buffer_alloc(w.buf[0], c);
 	buffer_alloc(w.buf[1], c);
@@ -452,7 +456,17 @@ int main(int argc, char **argv)
 		case 'v': c.verbose = 1; break;
 		case 'x': c.hex = 1; break;
 		case 'B': c.chunk = atol(optarg); break;
-		case 'D': c.dev = atoi(optarg); break;
+		case 'D':   // one device, or a comma-separated list: the workers are dealt over it
+			c.devs.clear();
+			for (const char *q = optarg; *q;) {
+				c.devs.push_back(atoi(q));
+				while (*q && *q != ',')
+					q++;
+				if (*q == ',')
+					q++;
+			}
+			c.dev = c.devs.empty() ? -1 : c.devs[0];
+			break;
 		case 'F': c.follow = 1; break;
 		case 'G': c.global_ws = atol(optarg); break;
 		case 'L': c.local_ws = atol(optarg); break;
@@ -528,7 +542,7 @@ int main(int argc, char **argv)
 		return 1;
 	}
 
-	// one automaton, one device copy, shared by all workers
+	// one automaton, one copy per device, shared by the workers of that device
 	acm_automaton *aut = acm_automaton_new();
 	if (acm_automaton_load_file(aut, c.pat_path.c_str(), c.hex, c.pat_limit) < 0) {
 		fprintf(stderr, "ERROR: init_ocl_worker_ctx\n%s\n", acm_last_error());
@@ -544,11 +558,15 @@ int main(int argc, char **argv)
 		sh.pat_iid.push_back(iid);
 		sh.pat_bytes.emplace_back((const char *)bytes, (size_t)n);
 	}
-	if (acm_dfa_upload(aut, c.dev, &sh.dfa) != ACM_OK) {
-		fprintf(stderr, "invalid dev pos\n%s\n", acm_last_error());
-		return 1;
+	for (int dev : c.devs) {
+		acm_dfa *dfa = nullptr;
+		if (acm_dfa_upload(aut, dev, &dfa) != ACM_OK) {
+			fprintf(stderr, "invalid dev pos\n%s\n", acm_last_error());
+			return 1;
+		}
+		sh.dfas.push_back(dfa);
 	}
-	const size_t automaton_bytes = acm_dfa_device_bytes(sh.dfa);
+	const size_t automaton_bytes = acm_dfa_device_bytes(sh.dfas[0]);
 	acm_automaton_free(aut);
 
 	signal(SIGINT, on_sigint);
@@ -557,6 +575,8 @@ int main(int argc, char **argv)
 	for (int i = 0; i < c.threads; i++) {
 		workers[i].sh = &sh;
 		workers[i].id = i;
+		workers[i].dev = c.devs[(size_t)i % c.devs.size()];
+		workers[i].dfa = sh.dfas[(size_t)i % c.devs.size()];
 		if (pthread_create(&workers[i].thread, nullptr, worker_main, &workers[i]) != 0) {
 			fprintf(stderr, "ERROR: creating thread: %d\n\n", i);
 			return 1;
@@ -587,6 +607,7 @@ int main(int argc, char **argv)
 	printf("Kernel launches:     %d\n", (int)rounds);
 	printf("Throughput (Mbps):   %.3f\n", ((double)(bytes * 8) / 1048576) / secs);
 	printf("-----------------------------------\n\n");
-	acm_dfa_release(sh.dfa);
+	for (acm_dfa *dfa : sh.dfas)
+		acm_dfa_release(dfa);
 	return 0;
 }

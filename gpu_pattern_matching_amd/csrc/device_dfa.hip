@@ -119,8 +119,12 @@ int build_sieve(const acm_automaton &a, acm_dfa *d)
 	}
 	d->sv_bloom_log_words = lw;
 	std::vector<uint32_t> bloom((size_t)1 << lw, 0);
-	for (const auto &kv : grams)
-		bloom[acm::sieve_bloom_word(kv.first, lw)] |= acm::sieve_bloom_bits(kv.first);
+	for (const auto &kv : grams) {
+		const uint32_t blk = acm::sieve_bloom_block(kv.first, lw);
+		const uint64_t bits = acm::sieve_bloom_bits(kv.first);
+		bloom[2 * blk] |= (uint32_t)bits;
+		bloom[2 * blk + 1] |= (uint32_t)(bits >> 32);
+	}
 
 	// gram table: buckets of four, one gram per bucket on average (a full bucket costs the
 	// lookup a second, dependent load: 2 % of the buckets)

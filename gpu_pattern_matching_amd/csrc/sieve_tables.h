@@ -31,7 +31,10 @@ constexpr uint32_t kSieveMaxLogWords = 15;
 // stride for a shortest pattern of m >= 3 bytes: the largest power of two W <= 8 with W + 2 <= m
 ACM_HD uint32_t sieve_stride(uint32_t m) { return m >= 10 ? 8u : m >= 6 ? 4u : m >= 4 ? 2u : 1u; }
 
-// ---- Bloom filter in LDS: both bits of a key in one word ---------------------
+// ---- Bloom filter in LDS: the four bits of a key in one 64-bit block ---------
+// (one ds_read_b64 per sample; a 32-bit block with two bits per key flags 0.8 % of random
+// samples against 16 000 keys in 64 KiB and 5 % against 120 000 in 128 KiB, this one 0.02 %
+// and 2 %)
 constexpr uint32_t kSieveMulA = 0x9E3779u, kSieveMulB = 0x85EBCAu, kSieveMulC = 0xC2B2AFu;   // 24-bit odd
 ACM_HD uint32_t mul24(uint32_t a, uint32_t b)
 {
@@ -41,11 +44,12 @@ ACM_HD uint32_t mul24(uint32_t a, uint32_t b)
 	return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu));
 #endif
 }
-ACM_HD uint32_t sieve_bloom_word(uint32_t gram, uint32_t log_words) { return mul24(gram, kSieveMulA) >> (32 - log_words); }
-ACM_HD uint32_t sieve_bloom_bits(uint32_t gram)
+// block index: log_words counts 32-bit words, a block is two of them
+ACM_HD uint32_t sieve_bloom_block(uint32_t gram, uint32_t log_words) { return mul24(gram, kSieveMulA) >> (33 - log_words); }
+ACM_HD uint64_t sieve_bloom_bits(uint32_t gram)
 {
 	const uint32_t p = mul24(gram, kSieveMulB);
-	return (1u << (p >> 27)) | (1u << ((p >> 22) & 31));
+	return (1ull << (p >> 26)) | (1ull << ((p >> 20) & 63)) | (1ull << ((p >> 14) & 63)) | (1ull << ((p >> 8) & 63));
 }
 
 // ---- gram table: buckets of four {gram | offset mask << 24}, 0 = empty -------

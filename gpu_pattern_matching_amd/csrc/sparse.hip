@@ -160,11 +160,11 @@ __device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh
 	return bits == 0 ? lo : bits >= 64 ? hi : (lo >> bits) | (hi << (64 - bits));
 }
 
-__device__ __forceinline__ uint32_t bloom_hit(const uint32_t *bloom, uint32_t gram, uint32_t word_shift)
+__device__ __forceinline__ uint32_t bloom_hit(const uint32_t *bloom, uint32_t gram, uint32_t block_shift)
 {
-	const uint32_t w = bloom[acm::mul24(gram, acm::kSieveMulA) >> word_shift];
+	const uint64_t w = ((const uint64_t *)bloom)[acm::mul24(gram, acm::kSieveMulA) >> block_shift];
 	const uint32_t p = acm::mul24(gram, acm::kSieveMulB);
-	return (w >> (p >> 27)) & (w >> ((p >> 22) & 31)) & 1u;
+	return (uint32_t)((w >> (p >> 26)) & (w >> ((p >> 20) & 63)) & (w >> ((p >> 14) & 63)) & (w >> ((p >> 8) & 63))) & 1u;
 }
 
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 	__builtin_amdgcn_s_barrier();   // (not __syncthreads: its fence would wait for the text as well)
 	if (DBG && stamp && lane == 0)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
-	const uint32_t word_shift = 32 - a.bloom_log_words;
+	const uint32_t word_shift = 33 - a.bloom_log_words;   // 64-bit blocks
 	const unsigned long long lt = (1ull << lane) - 1ull;   // the lanes in front of this one
 
 	uint32_t qn = 0;   // samples of the current tile written so far

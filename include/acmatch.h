@@ -315,6 +315,48 @@ int acm_remap_offsets(int32_t *d_off_plane, size_t max_records,
     void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* multi-GPU: shard plan and the gather of the match planes                */
+/* (new functionality: the reference takes one -D, ocl_aho_grep.c:498-502) */
+/* ---------------------------------------------------------------------- */
+
+/* One process (or thread) per device.  The text is cut by range: rank g of
+ * 'world' owns [begin, end) of the n bytes, loads load_bytes from load_begin
+ * on (its range and, in front of it, a halo of max_pattern_len - 1 bytes) and
+ * scans them with acm_scan_shard_async(halo, offset_shift): the records it
+ * reports are the serial scan's records that end in its range, with offsets
+ * in the coordinates of the whole text.  The DFA is replicated; nothing is
+ * exchanged during the scan. */
+typedef struct acm_shard_plan {
+	size_t begin, end;	/* the rank's share of the text              */
+	size_t halo;		/* context bytes in front of it               */
+	size_t load_begin;	/* first byte the rank reads (begin - halo)   */
+	size_t load_bytes;	/* bytes it scans, halo included              */
+	long offset_shift;	/* local offset + shift = offset in the text  */
+} acm_shard_plan;
+int acm_shard_plan_for(size_t n, int world, int rank, int max_pattern_len,
+    acm_shard_plan *out);
+
+/* The one exchange: every rank's compact planes (plane_capacity cells each)
+ * go to 'root' over RCCL -- nccl_comm is the caller's ncclComm_t; the sends and
+ * receives form one group on 'stream', point to point, nothing is
+ * synchronised.  On the root d_all_pat / d_all_off receive them rank-major,
+ * [world][plane_capacity]; other ranks may pass NULL.  librccl.so is loaded on
+ * first use. */
+int acm_gather_planes(void *nccl_comm, int rank, int world, int root,
+    const int32_t *d_pat_plane, const int32_t *d_off_plane,
+    size_t plane_capacity, int32_t *d_all_pat, int32_t *d_all_off,
+    void *stream);
+
+/* Host side of the root, after the gather has been copied back: rank order
+ * is position order, so the ranks' records back to back are the text's
+ * ordered list.  Writes them to pat_out / off_out (either may be NULL to only
+ * count), returns how many there are or an error; *last_state = the final
+ * state of the last rank's shard = the text's. */
+long acm_merge_planes(const int32_t *all_pat, const int32_t *all_off,
+    int world, size_t plane_capacity, int32_t *pat_out, int32_t *off_out,
+    size_t out_capacity, long *last_state);
+
+/* ---------------------------------------------------------------------- */
 /* device-runtime helpers for FFI hosts without a HIP binding              */
 /* ---------------------------------------------------------------------- */
 int acm_rt_set_device(int device);

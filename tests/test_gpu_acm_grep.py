@@ -78,6 +78,31 @@ def test_directory_workers_and_rounds(gpu, tmp_path):
     assert int(stats["Kernel launches"]) >= total // (32 * 4096)
 
 
+def test_device_list(gpu, tmp_path):
+    """-D takes a list of devices: worker i runs on entry i mod its length, every entry holds its
+    own copy of the automaton, the files are dealt to the workers as with one device
+    (ocl_aho_grep.c:87).  On a one-GPU box the list names device 0 twice: two copies, four workers,
+    same counts as the oracle; a device that does not exist is the reference's error."""
+    name = "clamav2000_m12"
+    o = fixtures.oracle_for(name)
+    pats = fixtures.patterns_of(name)
+    d = tmp_path / "inputs"
+    d.mkdir()
+    per_file = {}
+    for i in range(7):
+        t = fixtures.text_for({"kind": "clamav", "n": 200000 + 777 * i, "seed": 70 + i, "n_plant": 90}, pats)
+        (d / ("f%d.bin" % i)).write_bytes(t.tobytes())
+        per_file[str(d / ("f%d.bin" % i))] = t
+    sigs = orc.clamav_file(2000, str(tmp_path))
+    base = ["-f", str(d), "-p", sigs, "-x", "-m", "12", "-B", "4096", "-G", "32", "-L", "1024", "-w", "4"]
+    hits, stats, out = run(CLI, base + ["-D", "0,0"])
+    order = [os.path.join(str(d), e) for e in os.listdir(str(d))]
+    expect = sum(o.scan(np.concatenate([per_file[f] for f in order[w::4]]))[0].size for w in range(4))
+    assert int(stats["Matches"]) == expect and int(stats["Processed files"]) == 7
+    p = subprocess.run([CLI] + base + ["-D", "0,99"], capture_output=True, text=True, timeout=180, errors="replace")
+    assert p.returncode != 0 and "invalid dev pos" in p.stderr
+
+
 def test_text_mode(gpu, tmp_path):
     o = fixtures.oracle_for("sentiment")
     text = fixtures.text_for({"kind": "words", "n": 200000, "seed": 9}, None).tobytes()
