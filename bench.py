@@ -108,15 +108,16 @@ class Workload:
 
 
 class Pool:
-    """--workers host threads, parked between blocks (a thread per block would cost more than a step)."""
+    """--workers host threads: n - 1 parked between blocks (a thread per block would cost more than a
+    step) plus the caller, which takes the last share itself instead of sleeping through the block."""
 
     def __init__(self, n):
         self.n = n
-        self.go = threading.Barrier(n + 1)
-        self.done = threading.Barrier(n + 1)
+        self.go = threading.Barrier(n)
+        self.done = threading.Barrier(n)
         self.job = None
         self.err = []
-        self.threads = [threading.Thread(target=self._run, args=(i,), daemon=True) for i in range(n)]
+        self.threads = [threading.Thread(target=self._run, args=(i,), daemon=True) for i in range(n - 1)]
         for t in self.threads:
             t.start()
 
@@ -134,6 +135,10 @@ class Pool:
     def run(self, job):
         self.job = job
         self.go.wait()
+        try:
+            job(self.n - 1)
+        except Exception as e:
+            self.err.append(e)
         self.done.wait()
         if self.err:
             raise self.err[0]
@@ -214,19 +219,31 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         return out
 
     plain, profiled = batches(False), batches(True)
-    pool = Pool(W) if (W > 1 and not args.no_threads) else None
-    enq = matcher.lib.acm_scan_batch_async
+    native = args.issue == "native"
+    pool = Pool(W) if (W > 1 and args.issue == "threads") else None
+    enq, enq_many = matcher.lib.acm_scan_batch_async, matcher.lib.acm_scan_batches_async
     dfa = matcher.dfa
+    Batch = type(plain[0])
+    # the steps of a block as arrays for acm_scan_batches_async: all of them in step order (native),
+    # or worker w's share (threads)
+    whole = {id(bs): (Batch * K)(*bs) for bs in (plain, profiled)}
+    share = {id(bs): [(Batch * len(bs[w::W]))(*bs[w::W]) for w in range(W)] for bs in (plain, profiled)}
 
     def issue(bs, count):
-        """count steps, step k on worker k % W; every worker's steps come from its own host thread."""
+        """count steps, step k on worker (stream) k % W.  threads: every worker's steps are enqueued by
+        its own host thread with one acm_scan_batches_async call; native: one call from this thread
+        enqueues them all in step order; main: this thread, one FFI call per step."""
         def job(w):
-            for k in range(w, count, W):
-                rc = enq(dfa, C.byref(bs[k]))
-                if rc:
-                    check(rc, "acm_scan_batch_async")
+            mine = len(range(w, count, W))
+            rc = enq_many(dfa, share[id(bs)][w], mine) if mine else 0
+            if rc:
+                check(rc, "acm_scan_batches_async")
         t = time.perf_counter()
-        if pool is not None:
+        if native:
+            rc = enq_many(dfa, whole[id(bs)], count)
+            if rc:
+                check(rc, "acm_scan_batches_async")
+        elif pool is not None:
             pool.run(job)
         else:
             for k in range(count):
@@ -388,6 +405,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "pipeline": path,
                 "batches_in_flight": W,
                 "host_threads": W if pool is not None else 1,
+                "issue": args.issue,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
             },
@@ -447,7 +465,9 @@ def main():
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=4, help="batches in flight: HIP streams, one host thread each")
-    ap.add_argument("--no-threads", action="store_true", help="issue every step from the main thread")
+    ap.add_argument("--issue", default="threads", choices=["threads", "native", "main"],
+                    help="who enqueues the steps: one host thread per worker, one acm_scan_batches_async call, "
+                         "or the main thread step by step")
     ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
                     help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -500,8 +520,8 @@ def main():
         for name in args.sub.split(","):
             if not name or name == args.workload:
                 continue
-            rec = run_workload(ctx, Workload(name, args.plant), max(args.workers, args.steps // 4), args.warmup,
-                               min(3, args.repeats), min(4, max(1, args.texts)), args.workers, not args.no_verify, False)
+            rec = run_workload(ctx, Workload(name, args.plant), args.steps, args.warmup, args.repeats,
+                               min(4, max(1, args.texts)), args.workers, not args.no_verify, False)
             if rec is not None:
                 subs[name] = rec
 

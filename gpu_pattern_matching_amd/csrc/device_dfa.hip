@@ -96,7 +96,12 @@ int build_sieve(const acm_automaton &a, acm_dfa *d)
 	if (a.patterns.empty() || shortest < 3)
 		return ACM_OK;
 	const uint32_t n = a.num_states, F = a.first_final;
-	const uint32_t W = acm::sieve_stride((uint32_t)std::min<size_t>(shortest, 64));
+	uint32_t W = acm::sieve_stride((uint32_t)std::min<size_t>(shortest, 64));
+	if (const char *e = getenv("ACM_SIEVE_STRIDE")) {   // debugging aid: a smaller stride than the set allows
+		const uint32_t v = (uint32_t)atoi(e);
+		if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= W)
+			W = v;
+	}
 	const uint32_t D = (uint32_t)std::min<size_t>(shortest, acm::kSieveMaxPrefix);
 	d->sv_stride = W;
 	d->sv_prefix_len = D;

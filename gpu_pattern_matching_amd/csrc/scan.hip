@@ -858,6 +858,18 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	return acm_scan_batch_async(d, &b);
 }
 
+extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *batches, size_t count)
+{
+	if (!batches && count)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_batches_async: null batches");
+	for (size_t i = 0; i < count; i++) {
+		const int rc = acm_scan_batch_async(d, &batches[i]);
+		if (rc != ACM_OK)
+			return rc;
+	}
+	return ACM_OK;
+}
+
 namespace acm {
 int scan_prepare(const acm_dfa *)
 {

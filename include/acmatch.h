@@ -216,6 +216,12 @@ int acm_expand_matches_async(const acm_dfa *, const int32_t *d_state_plane,
 
 int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
 
+/* count batches with one call, enqueued in array order, each on its own
+ * stream: what a worker pool issues per round, without a trip through the
+ * FFI per batch.  Stops at the first batch that fails and returns its status
+ * (the batches before it stay enqueued). */
+int acm_scan_batches_async(const acm_dfa *, const acm_scan_batch *batches, size_t count);
+
 /* independent chains each lane interleaves in the walk kernel: 2 or 4.
  * Returns the value in use. */
 int acm_scan_set_chains_per_lane(acm_dfa *, int chains);
