@@ -43,8 +43,8 @@ struct acm_dfa {
 	void *arena = nullptr;               // one allocation for the small tables (device_dfa.hip, upload_small)
 	size_t arena_bytes = 0, arena_used = 0;
 
-	// adaptive AUTO mode (scan.hip, pick_sparse): batches the sparse kernels gave up on, counted by
-	// the device in pinned host memory
+	// adaptive AUTO mode (scan.hip, pick_sparse): sparse batches that turned out dense in matches,
+	// counted by the device in pinned host memory
 	uint32_t *h_giveups = nullptr, *d_giveups = nullptr;
 	mutable std::atomic<uint32_t> sparse_batches{0}, giveups_seen{0}, chain_hold{0};
 

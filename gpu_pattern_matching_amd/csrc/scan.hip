@@ -780,10 +780,11 @@ extern "C" int acm_scan_set_chains_per_lane(acm_dfa *d, int chains)
 extern "C" int acm_scan_kernel_count(void) { return 4; }
 
 namespace {
-// Which pipeline the next batch gets.  Tiny texts are not worth the extra launches.  In AUTO
-// mode the choice adapts: a batch the sparse kernels give up on costs both pipelines, so when
-// half of the last 16 sparse batches ended that way (dense matches, endless deep runs) the next
-// 64 go to the chain pipeline directly, then the sparse one is tried again.
+// Which pipeline the next batch gets.  Tiny texts are not worth the sieve's tables.  In AUTO
+// mode the choice adapts: the sparse pipeline is exact on any text but slow on one that is dense
+// in matches (more than a record per 128 bytes: its emit kernel counts such batches), so when
+// half of the last 16 sparse batches were dense the next 64 go to the chain pipeline, then the
+// sparse one is tried again.
 bool pick_sparse(const acm_dfa *d, size_t n)
 {
 	if (!d->sparse_ok || d->scan_mode == ACM_SCAN_MODE_CHAIN || n < 64)
@@ -796,7 +797,7 @@ bool pick_sparse(const acm_dfa *d, size_t n)
 			return false;
 	const uint32_t count = d->sparse_batches.fetch_add(1, std::memory_order_relaxed) + 1;
 	if (count % 16 == 0) {
-		const uint32_t seen = *(volatile uint32_t *)d->h_giveups;   // written by k_sparse_emit, may lag
+		const uint32_t seen = *(volatile uint32_t *)d->h_giveups;   // written by k_sieve_emit, may lag
 		const uint32_t before = d->giveups_seen.exchange(seen, std::memory_order_relaxed);
 		if (seen - before >= 8)
 			d->chain_hold.store(64, std::memory_order_relaxed);

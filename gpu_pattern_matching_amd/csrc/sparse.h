@@ -21,8 +21,7 @@ int sparse_prepare(const acm_dfa *d);
 
 // Enqueue the sparse pipeline for 'b' on stream s (three kernels; it always produces the planes).
 // after_sieve / after_emit: events to record behind the two kernels, or null.
-// path_marker: device word that receives ACM_SCAN_MODE_SPARSE (the chain kernels overwrite it
-// with 3 when they take over).
+// path_marker: device word that receives ACM_SCAN_MODE_SPARSE.
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
     uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit);
 

@@ -2,7 +2,7 @@
 // trie-path followers -> ordered emit.  gfx950 only.  Same contract and output as
 // the chain pipeline of scan.hip (it is the second implementation of
 // acm_scan_*_async, for pattern sets whose shortest pattern has at least 3
-// bytes); scan.hip stays the general path and the in-enqueue fallback.
+// bytes); scan.hip stays the general path.
 //
 // Why it is exact.  The serial DFA state at text position e is the longest suffix
 // of the text that is a trie node; call its first byte the START of e.  Let m be
@@ -20,7 +20,7 @@
 //     3-gram occurs at, and the prefix table whether text[p-o .. p-o+D) is a trie
 //     path: what survives is a FOLLOWER (s, depth-D node).
 //  3. Follow.  A follower walks its own path only: compare the text with the
-//     single outgoing edge (16 bytes per load along unary runs) or pick the child
+//     single outgoing edge (64 bytes per load level along unary runs) or pick the child
 //     from a short edge list; the first mismatch ends it.  No fail links: the
 //     suffix the DFA would fall back to starts later and has its own follower.
 //     extent(s) = last position its path reaches.  It notes the final nodes it
@@ -41,15 +41,25 @@
 // follower with the smallest start that is alive at the last byte, else the DFA
 // state after the last D-1 bytes from the root (depth < D there).
 //
-// Two launches:
-//   k_sieve       persistent workgroups; a wave owns a tile of the text: reads it
-//                 16 B per lane, probes, checks and follows what is flagged, keeps
-//                 the tile's hits in position order, writes a 32-byte tile summary
-//   k_sieve_emit  exclusive prefix max / prefix sum over the tile summaries, drops
-//                 the shadowed head of each list, copies the records to the planes
-// Work is capped (hits per tile, followers per sample, hits per follower); a text
-// beyond the caps sets a gate word and the chain pipeline, enqueued right behind
-// as early-exit launches, produces the planes instead.
+// Three launches, no host round trip between them:
+//   k_sieve        the bulk pass.  One workgroup of 16 waves per CU with the Bloom filter
+//                  in LDS; a wave owns a tile of the text at a time: reads it 16 B per
+//                  lane, probes one 3-gram per W bytes, appends {position, 3-gram} of what
+//                  the filter flags to the tile's sample list (ranks from ballots).
+//                  Nothing in it waits on a dependent load: HBM roofline.
+//   k_sieve_check  the exact part.  A wave takes the sample lists of four tiles: gram and
+//                  prefix lookups for 64 samples at a time (stage 1), then 64 followers
+//                  at a time (stage 2), shadow inside the wave, hits appended to the
+//                  wave's row in position order, a 32-byte row summary.  Latency-bound,
+//                  a thousand waves of dependent loads; it runs beside the next batch's
+//                  bulk pass.  Its last workgroup walks the carried state instead.
+//   k_sieve_emit   exclusive prefix max / prefix sum over the row summaries, drops the
+//                  shadowed head of each row, copies the records to the planes.
+// Nothing is capped and nothing falls back: a tile's sample list has room for every
+// sample of the tile and a row's hit list for one hit per position its followers can
+// reach (geometry_for); the lists are address space, only what is written is touched.
+// A text that is dense in matches is merely slow here -- the emit kernel counts such
+// batches and AUTO mode moves to the chain pipeline of scan.hip (pick_sparse).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -168,11 +168,13 @@ int acm_scan_set_chain_bytes(acm_dfa *, int chain_bytes);
 /*
  * Everything acm_scan_shard_async takes, plus two optional hipEvent_t for
  * keeping several batches in flight on different streams (what the
- * reference does with its -w workers, one queue each): the walk kernel is
- * the stage that fills the device, so consecutive batches are chained
- * through it -- batch k+1's walk waits for wait_before_walk (recorded by
- * batch k as record_after_walk) -- while everything behind a walk runs
- * concurrently with the next batch's walk.
+ * reference does with its -w workers, one queue each): the first kernel
+ * of a pipeline (chain: the walk, sparse: the bulk pass) is the stage that
+ * fills the device, so consecutive batches can be chained through it --
+ * batch k+1's first kernel waits for wait_before_walk (recorded by batch k
+ * as record_after_walk) -- while everything behind it runs concurrently
+ * with the next batch's first kernel.  Optional: independent streams alone
+ * overlap as well, and that is what bench.py measures.
  */
 typedef struct acm_scan_batch {
 	const void *d_text;
@@ -242,14 +244,14 @@ int acm_scan_set_graphs(acm_dfa *, int enable);
 
 /* Which pipeline acm_scan_*_async runs.  Both produce the same planes.
  *   CHAIN   speculative chains (any pattern set)
- *   SPARSE  trigram filter + candidate walks; needs every pattern to have
- *           at least 3 bytes (otherwise CHAIN is used); texts that exceed its
- *           per-walker caps are redone by the chain pipeline inside the same
- *           enqueue, decided on the device
- *   AUTO    SPARSE when the pattern set allows it -- adaptively: a batch the
- *           sparse kernels give up on costs both pipelines, so when half of
- *           the last 16 sparse batches ended that way the next 64 go to the
- *           chain pipeline directly, then the sparse one is tried again
+ *   SPARSE  strided 3-gram sieve + exact checks + trie-path followers; needs
+ *           every pattern to have at least 3 bytes (otherwise CHAIN is used).
+ *           Exact on any text, three launches, no fallback; slow on a text
+ *           that is dense in matches
+ *   AUTO    SPARSE when the pattern set allows it -- adaptively: when half of
+ *           the last 16 sparse batches held more than a record per 128 bytes
+ *           the next 64 go to the chain pipeline, then the sparse one is
+ *           tried again
  * Returns the mode in use after the call; acm_scan_mode(d, -1) only queries. */
 enum { ACM_SCAN_MODE_AUTO = 0, ACM_SCAN_MODE_CHAIN = 1, ACM_SCAN_MODE_SPARSE = 2 };
 int acm_scan_set_mode(acm_dfa *, int mode);
@@ -257,13 +259,14 @@ int acm_scan_set_mode(acm_dfa *, int mode);
 int acm_scan_sparse_eligible(const acm_dfa *);
 /* after a scan of n bytes with this workspace has been enqueued on stream:
  * waits for the stream and says which pipeline produced the planes --
- * ACM_SCAN_MODE_CHAIN, ACM_SCAN_MODE_SPARSE, or 3 = sparse gave up, chain redid it */
+ * ACM_SCAN_MODE_CHAIN or ACM_SCAN_MODE_SPARSE (0xDEAD: the sparse kernels found
+ * their own workspace inconsistent and wrote empty planes; cannot happen) */
 int acm_scan_path_taken(const acm_dfa *, const void *d_workspace, size_t n, void *stream);
 
 /* in-line timing with HIP events on the launch stream: when enabled, every
  * acm_scan_async records an event before its first kernel, after its first
- * kernel (chain: the walk; sparse: the trigram filter), after its second
- * (sparse: the candidate walk; chain: none, 0 ms) and after its last.
+ * kernel (chain: the walk; sparse: the bulk kernel k_sieve) and after its
+ * last.
  * acm_scan_profile_read waits for the recorded events, returns the summed
  * milliseconds of the first kernel, the second, and the whole pipeline over
  * 'launches' calls, and resets the accumulation.  (Sparse pipeline: first =

@@ -1,7 +1,7 @@
 /*
  * oracle/ref_harness.c -- thin accessors around the reference's own acsmx.c.
  *
- * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  This file is linked with
+ * TEST INFRASTRUCTURE ONLY (see the header of oracle/acref.c and DESIGN.md section 2).  This file is linked with
  * /root/reference/acsmx.c and utils.c, compiled where they lie (never copied)
  * by oracle/Makefile into oracle/_ref/libacsmx_ref.so.  It runs the
  * reference's acsm_new / acsm_add_pattern / acsm_compile unmodified and reads
