@@ -200,7 +200,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     W = max(1, workers)
     K = max(W, steps)
     streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
-    wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    # a worker's consecutive steps alternate between G workspaces: acm_scan_batches_async then puts
+    # up to G of them into one set of launches (--group 1: every step has its own three launches)
+    G = max(1, min(args.group, 4))
+    G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
+    wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
     # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
     # the check, else a ring of slots per worker
     slots = K if (world > 1 or K * cap * 8 <= (512 << 20)) else min(K, max(W * 2, ntexts))
@@ -214,7 +218,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         for k in range(K):
             w, p = k % W, planes[k % slots]
             out.append(matcher.make_batch(d_texts[k % ntexts], n_local, streams[w].cuda_stream, p[0], p[1], cap,
-                                          (wss[w], ws_bytes), halo=plan["halo"], offset_shift=plan["offset_shift"],
+                                          (wss[w][(k // W) % G], ws_bytes), halo=plan["halo"],
+                                          offset_shift=plan["offset_shift"],
                                           profile=profile and w == 0 and (k // W) % pe == 0))
         return out
 
@@ -296,11 +301,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     scratch = torch.zeros((2, cap), dtype=torch.int32, device=dev)
     for i in range(12):
         matcher.enqueue(matcher.make_batch(d_texts[i % ntexts], n_local, streams[0].cuda_stream, scratch[0], scratch[1],
-                                           cap, (wss[0], ws_bytes), halo=plan["halo"],
+                                           cap, (wss[0][0], ws_bytes), halo=plan["halo"],
                                            offset_shift=plan["offset_shift"], profile=True))
         torch.cuda.synchronize()
     s_k1, s_k2, s_pipe, s_n = matcher.profile_read()
-    path = matcher.path_taken(n_local, streams[0].cuda_stream, workspace=(wss[0].data_ptr(), ws_bytes))
+    path = matcher.path_taken(n_local, streams[0].cuda_stream, workspace=(wss[0][0].data_ptr(), ws_bytes))
 
     red = dev if ctx["backend"] == "nccl" else torch.device("cpu")
     if world > 1:
@@ -322,7 +327,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             with torch.cuda.stream(streams[w]):
                 stage[w][:n_local].copy_(pinned[k % len(pinned)], non_blocking=True)
             matcher.scan_async(stage[w], n_local, 0, streams[w].cuda_stream, scratch[0], scratch[1], cap,
-                               workspace=(wss[w], ws_bytes))
+                               workspace=(wss[w][0], ws_bytes))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         e2e = {"value": round(SHARD * ne / dt / 1e9, 2), "unit": "GB/s", "steps": ne,
@@ -403,9 +408,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "distinct_texts": ntexts,
                 "text_residency": residency,
                 "pipeline": path,
-                "batches_in_flight": W,
+                "workers": W,
+                "batches_in_flight": W * (G if (path == "sparse" and args.issue != "main") else 1),
                 "host_threads": W if pool is not None else 1,
                 "issue": args.issue,
+                "batches_per_launch_group": G if (path == "sparse" and args.issue != "main") else 1,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
             },
@@ -465,6 +472,8 @@ def main():
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=4, help="batches in flight: HIP streams, one host thread each")
+    ap.add_argument("--group", type=int, default=4,
+                    help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..4")
     ap.add_argument("--issue", default="threads", choices=["threads", "native", "main"],
                     help="who enqueues the steps: one host thread per worker, one acm_scan_batches_async call, "
                          "or the main thread step by step")

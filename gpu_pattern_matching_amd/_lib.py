@@ -74,6 +74,7 @@ NATIVE_API = {
                                        C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "acm_scan_batch_async": (C.c_int, [_vp, C.POINTER(ScanBatch)]),
     "acm_scan_batches_async": (C.c_int, [_vp, C.POINTER(ScanBatch), C.c_size_t]),
+    "acm_scan_set_max_group": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_chain_bytes": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_chains_per_lane": (C.c_int, [_vp, C.c_int]),
     "acm_scan_kernel_count": (C.c_int, []),

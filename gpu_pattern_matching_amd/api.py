@@ -253,6 +253,17 @@ class Matcher:
         if rc:
             check(rc, "acm_scan_batch_async")
 
+    def enqueue_many(self, batches):
+        """acm_scan_batches_async: the batches in order with one foreign call; consecutive sparse
+        batches of one size on one stream with their own workspaces and planes share their launches."""
+        arr = (_lib.ScanBatch * len(batches))(*batches)
+        rc = self.lib.acm_scan_batches_async(self.dfa, arr, len(batches))
+        if rc:
+            check(rc, "acm_scan_batches_async")
+
+    def set_max_group(self, batches):
+        return int(self.lib.acm_scan_set_max_group(self.dfa, int(batches)))
+
     def fetch(self, stream=None):
         """(offsets u32[], patterns i32[], last_state) of the last scan."""
         st = stream if stream is not None else self.stream

@@ -22,7 +22,7 @@ struct acm_dfa {
 	uint16_t *d_hot = nullptr;           // [hot_rows][256]
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
-	uint8_t *d_in_byte = nullptr;        // [states + 96] byte on the edge into dev state
+	uint8_t *d_in_byte = nullptr;        // [states + 224] byte on the edge into dev state
 	uint16_t *d_depth = nullptr;         // [states] trie depth of each state (carried-state walker of the sparse pipeline)
 
 	// sparse ("sieve") pipeline tables, sieve_tables.h
@@ -73,6 +73,7 @@ struct acm_dfa {
 		uint64_t last_use;
 	};
 	static constexpr size_t kMaxGraphs = 32;
+	int max_group = 4;                   // batches acm_scan_batches_async puts into one set of sparse launches
 	mutable bool use_graphs = false;     // opt-in: measured neutral on this stack
 	mutable std::vector<GraphEntry> graphs;
 	mutable std::vector<void *> parked_graphs;   // evicted execs, destroyed by acm_dfa_release

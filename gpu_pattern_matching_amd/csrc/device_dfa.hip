@@ -25,7 +25,7 @@
 //   out    i32 [states]         pattern index a final state reports (the head
 //                               of its match list, acsmx.c:650), -1 otherwise
 //   dev2ref u32 [states]        back to the reference's numbering (last_state)
-//   in_byte u8 [states + 96]    byte on the trie edge into each state; along
+//   in_byte u8 [states + 224]    byte on the trie edge into each state; along
 //                               a unary path the states ahead are d+1, d+2, ...
 //                               so 16 expected bytes are one contiguous load
 #include <hip/hip_runtime.h>
@@ -270,7 +270,7 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 			hot[i] = (uint16_t)((t < acm::kHotSentinel && t < F) ? t : acm::kHotSentinel);
 		}
 		std::vector<int32_t> outp(n);
-		std::vector<uint8_t> inb((size_t)n + 96, 0);
+		std::vector<uint8_t> inb((size_t)n + 224, 0);   // (the followers read up to 192 bytes past a state's own)
 		for (uint32_t s = 0; s < n; s++) {
 			const uint32_t r = a->dev2ref[s];
 			outp[s] = a->is_final_ref(r) ? a->head_of(r) : -1;

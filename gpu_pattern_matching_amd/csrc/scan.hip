@@ -859,16 +859,76 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 	return acm_scan_batch_async(d, &b);
 }
 
+namespace {
+bool pick_sparse(const acm_dfa *d, size_t n);
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer);
+
+// consecutive sparse batches of one size on one stream, each with its own workspace and planes,
+// that wait for nothing and are not timed: one group for the sparse kernels
+bool groupable(const acm_dfa *d, const acm_scan_batch &b)
+{
+	return !d->profile && !b.profile && !b.wait_before_walk && !b.record_after_walk && b.n > 0;
+}
+bool joins(const acm_scan_batch *const *group, uint32_t m, const acm_scan_batch &b)
+{
+	if (b.stream != group[0]->stream || b.n != group[0]->n)
+		return false;
+	for (uint32_t i = 0; i < m; i++)
+		if (b.d_workspace == group[i]->d_workspace || b.d_pat_plane == group[i]->d_pat_plane ||
+		    b.d_off_plane == group[i]->d_off_plane)
+			return false;
+	return true;
+}
+}  // namespace
+
 extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *batches, size_t count)
 {
 	if (!batches && count)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_batches_async: null batches");
+	if (!d || d->use_graphs || d->max_group <= 1) {
+		for (size_t i = 0; i < count; i++) {
+			const int rc = acm_scan_batch_async(d, &batches[i]);
+			if (rc != ACM_OK)
+				return rc;
+		}
+		return ACM_OK;
+	}
+	const uint32_t cap = std::min<uint32_t>((uint32_t)d->max_group, acm::sparse_max_group());
+	const acm_scan_batch *group[8];
+	uint32_t m = 0;
+	auto flush = [&]() -> int {
+		int rc = ACM_OK;
+		if (m == 1) {
+			rc = enqueue_batch(d, group[0], true, nullptr);
+		} else if (m > 1) {
+			acm::SieveJob jobs[8];
+			for (uint32_t i = 0; i < m && rc == ACM_OK; i++)
+				rc = enqueue_batch(d, group[i], true, &jobs[i]);
+			if (rc == ACM_OK)
+				rc = acm::sparse_group_enqueue(d, jobs, m, (hipStream_t)group[0]->stream, nullptr, nullptr);
+		}
+		m = 0;
+		return rc;
+	};
 	for (size_t i = 0; i < count; i++) {
-		const int rc = acm_scan_batch_async(d, &batches[i]);
+		const acm_scan_batch &b = batches[i];
+		const bool sparse = pick_sparse(d, b.n);   // (counts the batch: once per batch)
+		if (sparse && groupable(d, b)) {
+			if (m && (m >= cap || !joins(group, m, b))) {
+				const int rc = flush();
+				if (rc != ACM_OK)
+					return rc;
+			}
+			group[m++] = &b;
+			continue;
+		}
+		int rc = flush();
+		if (rc == ACM_OK)
+			rc = enqueue_batch(d, &b, sparse, nullptr);
 		if (rc != ACM_OK)
 			return rc;
 	}
-	return ACM_OK;
+	return flush();
 }
 
 namespace acm {
@@ -883,7 +943,7 @@ int scan_prepare(const acm_dfa *)
 }  // namespace acm
 
 namespace {
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse);
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer = nullptr);
 
 // what a cached graph was captured for: every input of enqueue_batch except the stream
 acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b, bool sparse)
@@ -1003,6 +1063,15 @@ extern "C" int acm_scan_batch_async(const acm_dfa *d, const acm_scan_batch *batc
 	return ACM_OK;
 }
 
+extern "C" int acm_scan_set_max_group(acm_dfa *d, int batches)
+{
+	if (!d)
+		return 1;
+	if (batches >= 1)
+		d->max_group = std::min<int>(batches, (int)acm::sparse_max_group());
+	return d->max_group;
+}
+
 extern "C" int acm_scan_set_graphs(acm_dfa *d, int enable)
 {
 	if (!d)
@@ -1013,7 +1082,9 @@ extern "C" int acm_scan_set_graphs(acm_dfa *d, int enable)
 }
 
 namespace {
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
+// defer: (sparse only) check and lay out as always, but leave the launches to the caller, who
+// enqueues a group of such batches with one set of kernels (acm_scan_batches_async)
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer)
 {
 	const void *d_text = batch->d_text;
 	const size_t n = batch->n, halo = batch->halo;
@@ -1129,6 +1200,13 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse)
 	if (profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
+	if (sparse && defer) {
+		defer->batch = batch;
+		defer->init_dev = a.init_state;
+		defer->sparse_ws = ws + l.sparse;
+		defer->path_marker = a.misc + 2;
+		return ACM_OK;
+	}
 	if (sparse) {   // three kernels of its own; it always produces the planes
 		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.misc + 2, s, ev[1], ev[2]);
 		if (rc != ACM_OK)

@@ -25,4 +25,16 @@ int sparse_prepare(const acm_dfa *d);
 int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
     uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit);
 
+// The same for up to sparse_max_group() batches of one size on one stream, with three launches
+// for all of them: every batch needs its own workspace and planes (they are in flight together).
+struct SieveJob {
+	const acm_scan_batch *batch;
+	uint32_t init_dev;       // device id of the batch's init_state
+	void *sparse_ws;         // the sparse part of the batch's workspace
+	uint32_t *path_marker;
+};
+uint32_t sparse_max_group();
+int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count, hipStream_t s, hipEvent_t after_sieve,
+    hipEvent_t after_emit);
+
 }  // namespace acm

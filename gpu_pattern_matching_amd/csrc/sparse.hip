@@ -47,7 +47,7 @@
 //                  lane, probes one 3-gram per W bytes, appends {position, 3-gram} of what
 //                  the filter flags to the tile's sample list (ranks from ballots).
 //                  Nothing in it waits on a dependent load: HBM roofline.
-//   k_sieve_check  the exact part.  A wave takes the sample lists of four tiles: gram and
+//   k_sieve_check  the exact part.  A wave takes the sample lists of eight tiles: gram and
 //                  prefix lookups for 64 samples at a time (stage 1), then 64 followers
 //                  at a time (stage 2), shadow inside the wave, hits appended to the
 //                  wave's row in position order, a 32-byte row summary.  Latency-bound,
@@ -82,7 +82,7 @@ using acm_dev::agree16;
 
 constexpr int kBlock = 1024;               // threads of a k_sieve workgroup
 constexpr int kWaves = kBlock / 64;
-constexpr uint32_t kTilesPerChecker = 4;   // tiles whose flagged samples one wave of k_sieve_check takes
+constexpr uint32_t kTilesPerChecker = 8;   // tiles whose flagged samples one wave of k_sieve_check takes
 constexpr int kCheckBlock = 64;            // threads of a k_sieve_check workgroup
 constexpr uint32_t kQ2Cap = 64 + 64 * 8;   // followers a checker queues: what a round leaves + 64 samples x 8 offsets
 constexpr uint32_t kMinTile = 1024;        // bytes; one 16-byte group per lane
@@ -134,6 +134,56 @@ struct SieveArgs {
 	uint32_t plane_capacity;
 };
 
+// A launch takes up to kMaxGroup batches of the same size (acm_scan_batches_async): the bulk
+// kernel's waves go through the tiles of one batch after the other, the check and emit kernels
+// get a share of workgroups per batch.  The kernels' fixed costs -- launch, filter fill, the
+// chains of dependent loads of the check kernel -- are paid once per group instead of once
+// per batch.
+constexpr uint32_t kMaxGroup = 4;
+// What travels in the argument buffer: the tables and the geometry once (a group's batches have
+// one size), 64 bytes per batch; a kernel puts the SieveArgs of its batch together from both (the
+// fields it does not use cost nothing).  An argument buffer of 4 x SieveArgs -- 1.2 KB -- made
+// every launch measurably slower.
+struct SieveBatch {
+	const uint8_t *text;
+	char *ws;                 // the sparse part of the batch's workspace
+	int32_t *pat_plane, *off_plane;
+	uint32_t *path_marker;
+	uint32_t init_state, drop_before;
+	int32_t off_shift;
+	uint32_t plane_capacity, report_state;
+};
+struct SieveGroup {
+	SieveArgs common;         // everything but the fields of SieveBatch and the workspace pointers
+	size_t o_summary, o_lists, o_samples, o_shead, o_lhead, o_scount, o_misc;   // byte offsets into ws
+	SieveBatch b[kMaxGroup];
+	uint32_t count;
+};
+__device__ __forceinline__ SieveArgs batch_view(const SieveGroup &g, uint32_t bi)
+{
+	SieveArgs a = g.common;
+	const SieveBatch &b = g.b[bi];
+	a.text = b.text;
+	a.text16 = (const uint4 *)b.text;
+	a.init_state = b.init_state;
+	a.drop_before = b.drop_before;
+	a.off_shift = b.off_shift;
+	a.report_state = b.report_state;
+	a.out = b.report_state ? (const int32_t *)g.common.dev2ref : g.common.out;
+	a.summary = (uint32_t *)(b.ws + g.o_summary);
+	a.lists = (uint2 *)(b.ws + g.o_lists);
+	a.samples = (uint2 *)(b.ws + g.o_samples);
+	a.shead = (uint2 *)(b.ws + g.o_shead);
+	a.lhead = (uint2 *)(b.ws + g.o_lhead);
+	a.scount = (uint32_t *)(b.ws + g.o_scount);
+	a.misc = (uint32_t *)(b.ws + g.o_misc);
+	a.pat_plane = b.pat_plane;
+	a.off_plane = b.off_plane;
+	a.plane_capacity = b.plane_capacity;
+	a.path_marker = b.path_marker;
+	return a;
+}
+
 // Both kinds of list are far longer than what they usually hold (a few samples per tile, a few
 // hits per row), and a row per page would cost every writer and reader an address translation:
 // the first kHead entries of each list live side by side in a small dense array, the rest (rare)
@@ -170,9 +220,14 @@ __device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh
 	return bits == 0 ? lo : bits >= 64 ? hi : (lo >> bits) | (hi << (64 - bits));
 }
 
-__device__ __forceinline__ uint32_t bloom_hit(const uint32_t *bloom, uint32_t gram, uint32_t block_shift)
+// the filter in two halves, so that the reads of many samples can be in flight before the first is
+// looked at: the key's 64-bit block (one ds_read_b64), then its four bits
+__device__ __forceinline__ uint64_t bloom_block(const uint32_t *bloom, uint32_t gram, uint32_t block_shift)
 {
-	const uint64_t w = ((const uint64_t *)bloom)[acm::mul24(gram, acm::kSieveMulA) >> block_shift];
+	return ((const uint64_t *)bloom)[acm::mul24(gram, acm::kSieveMulA) >> block_shift];
+}
+__device__ __forceinline__ uint32_t bloom_test(uint64_t w, uint32_t gram)
+{
 	const uint32_t p = acm::mul24(gram, acm::kSieveMulB);
 	return (uint32_t)((w >> (p >> 26)) & (w >> ((p >> 20) & 63)) & (w >> ((p >> 14) & 63)) & (w >> ((p >> 8) & 63))) & 1u;
 }
@@ -222,23 +277,25 @@ __device__ __forceinline__ void note_hit(LaneHits &h, uint32_t x, uint32_t value
 	h.n += take ? 1u : 0u;
 }
 
-// bytes the 64-byte windows at p and q agree on before the first difference (64: all).  All
-// eight loads are unconditional and in flight together: one latency for up to 64 bytes (a load
-// inside a branch gets its own wait: four round trips instead of one).
-__device__ __forceinline__ uint32_t agree64(const uint8_t *p, const uint8_t *q)
+// bytes the windows of CH * 16 bytes at p and q agree on before the first difference (CH * 16:
+// all).  All the loads are unconditional and in flight together: one latency for the whole window
+// (a load inside a branch gets its own wait: a round trip each instead of one).
+template <int CH>
+__device__ __forceinline__ uint32_t agree(const uint8_t *p, const uint8_t *q)
 {
-	uint64_t lo[4], hi[4];
+	uint64_t lo[CH], hi[CH];
 #pragma unroll
-	for (int k = 0; k < 4; k++)
+	for (int k = 0; k < CH; k++)
 		acm_dev::diff_bytes16(p + k * 16, q + k * 16, lo[k], hi[k]);
-	uint32_t same = 64;
+	uint32_t same = CH * 16;
 #pragma unroll
-	for (int k = 3; k >= 0; k--) {   // the earliest difference is written last
+	for (int k = CH - 1; k >= 0; k--) {   // the earliest difference is written last
 		same = hi[k] ? (uint32_t)k * 16 + 8 + (((uint32_t)__ffsll((long long)hi[k]) - 1u) >> 3) : same;
 		same = lo[k] ? (uint32_t)k * 16 + (((uint32_t)__ffsll((long long)lo[k]) - 1u) >> 3) : same;
 	}
 	return same;
 }
+constexpr uint32_t kLongLevel = 64;    // bytes a follower compares per load level along a unary run (192: fewer levels, but each slower -- measured)
 
 // One follower: from 'node' (depth D, last matched byte at x) along its trie path.
 // Returns extent + 1; at_end: the path was still alive at the last byte (on 'node').
@@ -278,11 +335,22 @@ __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32
 		if (x + 1 >= a.n)
 			break;
 		h.levels++;
+		uint4 rec;
+		uint32_t c;
 		if (run) {   // unary, non-final path ahead: node+1, node+2, ... as long as the text agrees
-			const uint32_t want = min(min(run, 64u), a.n - 1 - x);
+			// (a signature is one unary run from its prefix to its leaf more often than not: the whole of
+			// it in one level where the text has the room, 64 bytes near its end)
+			const bool roomy = x + 1 + kLongLevel <= a.n_pad;
+			const uint32_t step = min(run, roomy ? kLongLevel : 64u), want = min(step, a.n - 1 - x);
+			// with the compare, what the node at the end of the stretch needs if the stretch is the
+			// whole run: its record and the byte behind it -- one level instead of two
+			c = a.text[min(x + step + 1, a.n_pad - 1)];
+			rec = a.rec[node + step];
 			uint32_t same;
-			if (x + 65 <= a.n_pad) {
-				same = agree64(a.in_byte + node + 1, a.text + x + 1);
+			if (roomy) {
+				same = agree<kLongLevel / 16>(a.in_byte + node + 1, a.text + x + 1);
+			} else if (x + 65 <= a.n_pad) {
+				same = agree<4>(a.in_byte + node + 1, a.text + x + 1);
 			} else {
 				same = 0;
 				while (same < want && a.in_byte[node + 1 + same] == a.text[x + 1 + same])
@@ -292,12 +360,16 @@ __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32
 			node += k;
 			x += k;
 			run -= k;
-			if (k < want)
+			if (k < step)
+				break;   // a mismatch, or the end of the text
+			if (run)
+				continue;
+			if (x + 1 >= a.n)
 				break;
-			continue;
+		} else {
+			c = a.text[x + 1];   // both loads before anything looks at either
+			rec = a.rec[node];
 		}
-		uint32_t c = a.text[x + 1];   // both loads before anything looks at either
-		const uint4 rec = a.rec[node];
 		__asm__ volatile("" : "+v"(c));   // (keeps the byte's load from sinking into the branch that uses it)
 		const uint32_t nchild = rec.y & 0x1FFu;
 		uint32_t value;
@@ -313,15 +385,25 @@ __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32
 			value = a.report_state ? rec.w : rec.z;
 		} else {
 			const uint4 *e = a.edges + (rec.x & 0xFFFFFFu);
-			bool hit = false;
+			bool hit = false, past = false;
 			uint4 v = make_uint4(0, 0, 0, 0);
-			for (uint32_t i = 0; i < nchild && !hit; i++) {   // sorted by byte
-				v = e[i];
-				const uint32_t b = v.x & 0xFFu;
-				if (b == c)
-					hit = true;
-				else if (b > c)
-					break;
+			for (uint32_t i = 0; i < nchild && !hit && !past; i += 4) {   // sorted by byte; four edges a level
+				uint4 q[4];
+#pragma unroll
+				for (uint32_t j = 0; j < 4; j++)
+					q[j] = e[min(i + j, nchild - 1)];
+#pragma unroll
+				for (uint32_t j = 0; j < 4; j++) {
+					const uint32_t b = q[j].x & 0xFFu;
+					if (!hit && !past && i + j < nchild) {
+						if (b == c) {
+							hit = true;
+							v = q[j];
+						} else if (b > c) {
+							past = true;
+						}
+					}
+				}
 			}
 			if (!hit)
 				break;
@@ -648,8 +730,29 @@ __device__ __forceinline__ void wait_loads(v4u &x, uint32_t &y)
 // at a time, reads it 16 bytes per lane, tests one 3-gram per W bytes and writes the
 // samples the filter flags -- position and 3-gram -- to the tile's list in position order
 // (ranks from ballots: no scan, no LDS queue).  Nothing here waits on a dependent load.
+// What the bulk kernel needs of a batch, read from the argument buffer once per batch and pinned
+// in scalar registers (left to itself the compiler re-reads a field where it is used -- a scalar
+// load and an lgkmcnt(0) between the LDS probes, which then wait for each other).
+struct BulkBatch {
+	const uint4 *text16;
+	uint2 *shead, *samples;
+	uint32_t *scount;
+	uint32_t n, n_pad, tile_bytes, ntiles, scap;
+	__device__ __forceinline__ explicit BulkBatch(const SieveArgs &a)
+	    : text16(a.text16), shead(a.shead), samples(a.samples), scount(a.scount), n(a.n), n_pad(a.n_pad),
+	      tile_bytes(a.tile_bytes), ntiles(a.ntiles), scap(a.scap)
+	{
+		asm volatile("" : "+s"(text16), "+s"(shead), "+s"(samples), "+s"(scount));
+		asm volatile("" : "+s"(n), "+s"(n_pad), "+s"(tile_bytes), "+s"(ntiles), "+s"(scap));
+	}
+	__device__ __forceinline__ uint2 *slot(uint32_t tile, uint32_t idx) const
+	{
+		return idx < kSampleHead ? shead + (size_t)tile * kSampleHead + idx : samples + (size_t)tile * scap + idx;
+	}
+};
+
 template <int W, bool DBG>
-__global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
+__global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -658,8 +761,6 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 	constexpr uint32_t SUB = LOADS * 1024;                      // bytes of a sub-block
 	constexpr uint32_t SMASK = (1u << S) - 1u;
 	const uint32_t nwaves = gridDim.x * kWaves;
-	const uint32_t n16 = a.n_pad >> 4;
-	const uint32_t *text32 = (const uint32_t *)a.text16;
 
 	v4u w[LOADS];
 	uint32_t nx[LOADS];
@@ -669,7 +770,9 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 	// whatever exists of the tile (what does not exist is read at the start of the text and masked
 	// out): the waits count them.  Non-temporal: the text is read once, the tables the check kernel
 	// needs stay in L2.
-	auto issue = [&](uint32_t tile, uint32_t off) {
+	auto issue = [&](const BulkBatch &a, uint32_t tile, uint32_t off) {
+		const uint32_t n16 = a.n_pad >> 4;
+		const uint32_t *text32 = (const uint32_t *)a.text16;
 		present = 0;
 #pragma unroll
 		for (uint32_t j = 0; j < LOADS; j++) {
@@ -702,14 +805,19 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 		const uint32_t v = sh == 0 ? x[i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i], sh);
 		return v & 0xFFFFFFu;
 	};
-	uint32_t tile = blockIdx.x * kWaves + wv, off = 0;
-	unsigned long long *stamp = DBG && a.stamps ? a.stamps + (size_t)(blockIdx.x * kWaves + wv) * 8 : nullptr;
+	const uint32_t tile_first = blockIdx.x * kWaves + wv;
+	// every batch's scalars now, with the filter still on its way (fetched where a batch starts they
+	// would be a scalar-memory round trip in front of its first loads)
+	const BulkBatch b0(batch_view(g, 0)), b1(batch_view(g, 1)), b2(batch_view(g, 2)), b3(batch_view(g, 3));
+	static_assert(kMaxGroup == 4, "the bulk kernel's batch loop is unrolled four times");
+	unsigned long long *stamp = DBG && g.common.stamps ? g.common.stamps + (size_t)tile_first * 8 : nullptr;
 	if (DBG && stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	{
 		// The filter goes to LDS by DMA (no registers, nothing waits yet), 1 KiB pieces dealt over the
 		// waves; then the text loads; then a wait for the filter only -- the text keeps arriving
 		// while the first groups are probed.
+		const SieveArgs &a = g.common;
 		const uint32_t pieces = a.bloom_words / 256;
 		const uint32_t rot = (blockIdx.x * 7u) % pieces;   // the workgroups do not start on the same L2 channel
 		for (uint32_t c = wv; c < pieces; c += kWaves) {
@@ -725,75 +833,103 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
 			    : "=&s"(keep_m0) : "s"(lds_at), "v"(from) : "memory");
 		}
-		issue(tile, off);
+		issue(b0, tile_first, 0);
 		asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * PER) : "memory");
 	}
 	__builtin_amdgcn_s_barrier();   // (not __syncthreads: its fence would wait for the text as well)
 	if (DBG && stamp && lane == 0)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
-	const uint32_t word_shift = 33 - a.bloom_log_words;   // 64-bit blocks
+	const uint32_t word_shift = 33 - g.common.bloom_log_words;   // 64-bit blocks
 	const unsigned long long lt = (1ull << lane) - 1ull;   // the lanes in front of this one
 
-	uint32_t qn = 0;   // samples of the current tile written so far
 	bool first = true;
-	while (tile < a.ntiles) {
-		// A sub-block's loads are issued here and probed in order as they arrive (the first one's were
-		// issued above, in front of the filter's wait); the flagged samples are stored once all
-		// groups are probed.  Other waves of the CU cover the latency.
-		if (!first)
-			issue(tile, off);
-		first = false;
-		const uint32_t base = tile * a.tile_bytes + off;
-		uint32_t f = 0;
 #pragma unroll
-		for (uint32_t j = 0; j < LOADS; j++) {
-			const uint32_t pos0 = base + j * 1024 + lane * 16;
-			// samples whose 3-gram lies inside the text (none for groups that do not exist)
-			const bool loaded = ((present >> j) & 1u) && pos0 + 2 < a.n;
-			const uint32_t room = loaded ? (a.n - 2 - pos0 + W - 1) / W : 0u;
-			arrived(j);
-			uint32_t fj = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < S; k++)
-				fj |= (k < room ? bloom_hit(bloom, gram_of(j, k), word_shift) : 0u) << k;
-			f |= fj << (j * S);
-		}
-		if (DBG && stamp && lane == 0 && stamp[2] == 0)
-			stamp[2] = __builtin_amdgcn_s_memrealtime();
-		// the flagged samples go to the tile's list in position order: ranks from ballots
-		if (__ballot(f != 0)) {
-#pragma unroll
-			for (uint32_t j = 0; j < LOADS; j++) {
-				const uint32_t fj = (f >> (j * S)) & SMASK;
-				if (!__ballot(fj != 0))
-					continue;
+	for (uint32_t bi = 0; bi < kMaxGroup; bi++) {
+		if (bi >= g.count)
+			break;
+		const BulkBatch &a = bi == 0 ? b0 : bi == 1 ? b1 : bi == 2 ? b2 : b3;
+		uint32_t tile = tile_first, off = 0;
+		uint32_t qn = 0;   // samples of the current tile written so far
+		while (tile < a.ntiles) {
+			// A sub-block's loads are issued here and probed in order as they arrive (the very first
+			// one's were issued above, in front of the filter's wait); the flagged samples are stored
+			// once all groups are probed.  Other waves of the CU cover the latency.
+			if (!first)
+				issue(a, tile, off);
+			first = false;
+			const uint32_t base = tile * a.tile_bytes + off;
+			uint32_t f = 0;
+			// samples of group j whose 3-gram lies inside the text (none for groups that do not exist)
+			auto room_of = [&](uint32_t j) -> uint32_t {
 				const uint32_t pos0 = base + j * 1024 + lane * 16;
-				uint32_t before = 0, all = 0;
+				const bool loaded = ((present >> j) & 1u) && pos0 + 2 < a.n;
+				return loaded ? (a.n - 2 - pos0 + W - 1) / W : 0u;
+			};
+			// The filter blocks of two samples (a unit) are read together, as their group arrives
+			// and without a branch around the reads, and looked at one unit later: the LDS reads of two
+			// units are in flight instead of one sample's.  (Pinned below: left alone the compiler reads every
+			// block of the sub-block first and tests afterwards, 122 registers instead of 80.)
+			constexpr uint32_t U = 2, UPG = S / U, NU = LOADS * UPG;
+			uint64_t blk[2][U];
 #pragma unroll
-				for (uint32_t k = 0; k < S; k++) {
-					const unsigned long long bk = __ballot((fj >> k) & 1u);
-					before += (uint32_t)__popcll(bk & lt);
-					all += (uint32_t)__popcll(bk);
+			for (uint32_t u = 0; u <= NU; u++) {
+				if (u < NU) {
+					const uint32_t j = u / UPG, k0 = (u % UPG) * U;
+					if (k0 == 0)
+						arrived(j);
+#pragma unroll
+					for (uint32_t i = 0; i < U; i++)
+						blk[u & 1][i] = bloom_block(bloom, gram_of(j, k0 + i), word_shift);
 				}
+				if (u > 0) {
+					const uint32_t v = u - 1, j = v / UPG, k0 = (v % UPG) * U;
+					const uint32_t room = room_of(j);
 #pragma unroll
-				for (uint32_t k = 0; k < S; k++)
-					if ((fj >> k) & 1u) {
-						const uint32_t at = qn + before + (uint32_t)__popc(fj & ((1u << k) - 1u));
-						*sample_slot(a, tile, at) = make_uint2(pos0 + k * W, gram_of(j, k));
-					}
-				qn += all;
+					for (uint32_t i = 0; i < U; i++)
+						f |= (bloom_test(blk[v & 1][i], gram_of(j, k0 + i)) & (k0 + i < room ? 1u : 0u)) << (j * S + k0 + i);
+				}
+				// (an accumulated flag word nobody looks at before the end would let the compiler sink all the
+				// bit tests behind the last read, the blocks of the whole sub-block live until then)
+				asm volatile("" : "+v"(f));
+				__builtin_amdgcn_sched_barrier(0);
 			}
-		}
-		const uint32_t cur = tile;
-		off += SUB;
-		if (off >= a.tile_bytes) {
-			off = 0;
-			tile += nwaves;
-		}
-		if (tile != cur) {
-			if (lane == 0)
-				a.scount[cur] = qn;
-			qn = 0;
+			if (DBG && stamp && lane == 0 && stamp[2] == 0)
+				stamp[2] = __builtin_amdgcn_s_memrealtime();
+			// the flagged samples go to the tile's list in position order: ranks from ballots
+			if (__ballot(f != 0)) {
+#pragma unroll
+				for (uint32_t j = 0; j < LOADS; j++) {
+					const uint32_t fj = (f >> (j * S)) & SMASK;
+					if (!__ballot(fj != 0))
+						continue;
+					const uint32_t pos0 = base + j * 1024 + lane * 16;
+					uint32_t before = 0, all = 0;
+#pragma unroll
+					for (uint32_t k = 0; k < S; k++) {
+						const unsigned long long bk = __ballot((fj >> k) & 1u);
+						before += (uint32_t)__popcll(bk & lt);
+						all += (uint32_t)__popcll(bk);
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < S; k++)
+						if ((fj >> k) & 1u) {
+							const uint32_t at = qn + before + (uint32_t)__popc(fj & ((1u << k) - 1u));
+							*a.slot(tile, at) = make_uint2(pos0 + k * W, gram_of(j, k));
+						}
+					qn += all;
+				}
+			}
+			const uint32_t cur = tile;
+			off += SUB;
+			if (off >= a.tile_bytes) {
+				off = 0;
+				tile += nwaves;
+			}
+			if (tile != cur) {
+				if (lane == 0)
+					a.scount[cur] = qn;
+				qn = 0;
+			}
 		}
 	}
 	if (DBG && stamp && lane == 0)
@@ -807,39 +943,54 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveArgs a)
 // latency-bound, light on everything else -- it runs beside the next batch's bulk pass.
 // The last workgroup walks the carried state and the tail instead.
 template <int W>
-__global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
+__global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 {
 	__shared__ uint32_t q2[3][kQ2Cap];
 	const uint32_t lane = threadIdx.x;
-	if (blockIdx.x == gridDim.x - 1) {
+	// the workgroups of a launch are dealt over the group's batches, nrows each
+	const uint32_t per = g.common.nrows, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
+	const SieveArgs a = batch_view(g, bi);
+	if (blk == per - 1) {
 		if (threadIdx.x == 0)
 			side_walks(a);
 		return;
 	}
-	const uint32_t tile0 = blockIdx.x * kTilesPerChecker;
-	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blockIdx.x + 8192) * 8 : nullptr;
+	const uint32_t tile0 = blk * kTilesPerChecker;
+	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blk + 8192) * 8 : nullptr;
 	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
 	if (stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
-	const uint32_t row = blockIdx.x + 1;   // row 0 is the carried-state walker's
+	const uint32_t row = blk + 1;   // row 0 is the carried-state walker's
 	FollowerQueue fq;
 	fq.start = q2[0];
 	fq.node = q2[1];
 	fq.run = q2[2];
 	fq.count = 0;
-	// the lists of this wave's tiles, one behind the other
-	uint32_t mycount = 0;
-	if (lane < kTilesPerChecker && tile0 + lane < a.ntiles)
-		mycount = a.scount[tile0 + lane];
+	// the lists of this wave's tiles, one behind the other.  With the counts, in the same load
+	// level, the first samples of each tile, an equal share of the wave's lanes per tile: when no
+	// tile has more (nearly always) that is the first and only stage-1 round, lanes in position order.
+	constexpr uint32_t kSpecLanes = 64 / kTilesPerChecker;   // lanes (= samples) per tile in the speculative round
+	static_assert(64 % kTilesPerChecker == 0 && kSampleHead >= kSpecLanes, "the speculative first round deals the lanes evenly");
+	const uint32_t my_tile = tile0 + lane / kSpecLanes, my_idx = lane % kSpecLanes;
+	const bool tile_ok = my_tile < a.ntiles;
+	const uint32_t tile_c = tile_ok ? my_tile : tile0;
+	const uint32_t mycount = tile_ok ? a.scount[tile_c] : 0u;
+	const uint2 spec = a.shead[(size_t)tile_c * kSampleHead + my_idx];
 	uint32_t cum[kTilesPerChecker + 1];
 	cum[0] = 0;
 #pragma unroll
 	for (uint32_t k = 0; k < kTilesPerChecker; k++)
-		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)k);
+		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)(k * kSpecLanes));
 	const uint32_t nsamples = cum[kTilesPerChecker];
 	uint32_t r0 = 0;
+	if (nsamples && !__ballot(mycount > kSpecLanes)) {
+		dbg_rounds++;
+		dbg_cands += nsamples;
+		r0 = nsamples;
+		stage1_round<W>(a, fq, spec.x, spec.y, my_idx < mycount, lane);
+	}
 	for (;;) {
 		if (fq.count >= 64 || (r0 >= nsamples && fq.count > 0)) {   // stage 2: a round of followers
 			const uint32_t cnt = min(fq.count, 64u);
@@ -889,7 +1040,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveArgs a)
 		stage1_round<W>(a, fq, it.x, it.y, act, lane);
 	}
 	if (lane == 0)
-		write_summary(a, t, blockIdx.x + 1);
+		write_summary(a, t, row);
 	if (stamp && lane == 0) {
 		stamp[4] = __builtin_amdgcn_s_memrealtime();
 		stamp[5] = ((unsigned long long)dbg_rounds << 32) | dbg_cands;
@@ -934,15 +1085,17 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 // binary search in LDS and moves one record, so that the stores of a wave lie side by side.  (The
 // owner of a row copying the row's records itself, one predicated store per possible record,
 // took three times as long: it is the instruction count of 1024 threads that matters here.)
-__global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
+__global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 {
+	const uint32_t per = gridDim.x / g.count, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
+	const SieveArgs a = batch_view(g, bi);
 	__shared__ uint32_t lds[kEmitBlock / 64];
 	__shared__ uint32_t s_base[kMaxRows + 1];   // first output cell of each row
 	__shared__ uint32_t s_drop[kMaxRows];       // shadowed head of each row's list
 	__shared__ unsigned long long s_alive;
 	const uint32_t rows = a.nrows;
 	const uint32_t r0 = threadIdx.x * kRowsPerThread;
-	unsigned long long *stamp = a.stamps && threadIdx.x == 0 ? a.stamps + (size_t)(9000 + blockIdx.x) * 8 : nullptr;
+	unsigned long long *stamp = a.stamps && threadIdx.x == 0 ? a.stamps + (size_t)(9000 + blk) * 8 : nullptr;
 	if (stamp)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	// every kernel argument the kernel will need, fetched now, together (the compiler would fetch each
@@ -974,7 +1127,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 			alive = min(alive, ((unsigned long long)al.x << 32) | al.y);
 	}
 	if (__syncthreads_or(gave ? 1 : 0)) {   // cannot happen (geometry_for): say so instead of writing planes
-		if (blockIdx.x == 0 && threadIdx.x == 0) {
+		if (blk == 0 && threadIdx.x == 0) {
 			*a.path_marker = kMarkerFailed;
 			a.pat_plane[0] = a.off_plane[0] = 0;
 		}
@@ -1019,7 +1172,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 			s_base[rows] = all_cells;
 		__syncthreads();
 		// one thread per output cell: find the row it belongs to, copy the record
-		for (uint32_t c = blockIdx.x * kEmitBlock + threadIdx.x; c < all_cells; c += gridDim.x * kEmitBlock) {
+		for (uint32_t c = blk * kEmitBlock + threadIdx.x; c < all_cells; c += per * kEmitBlock) {
 			uint32_t lo = 0, hi = rows;   // the row r with s_base[r] <= c < s_base[r + 1]
 			while (hi - lo > 1) {
 				const uint32_t mid = (lo + hi) >> 1;
@@ -1037,7 +1190,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveArgs a)
 	}
 	if (stamp)
 		stamp[3] = __builtin_amdgcn_s_memrealtime();
-	if (blockIdx.x == 0 && threadIdx.x == 0) {   // header and trailer cells
+	if (blk == 0 && threadIdx.x == 0) {   // header and trailer cells
 		const unsigned long long k = s_alive;
 		const uint32_t last_dev = k != ~0ull ? (uint32_t)k : a.misc[0];
 		const int32_t last_ref = (int32_t)a.dev2ref[last_dev];
@@ -1110,13 +1263,12 @@ int sparse_prepare(const acm_dfa *)
 	return ACM_OK;
 }
 
-int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
-    uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit)
+namespace {
+// the shared part of a group's kernel arguments: tables, geometry for texts of n bytes, workspace layout
+void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 {
-	const size_t n = b->n;
-	const Geometry g = geometry_for(d, n);
-	SieveArgs a;
-	memset(&a, 0, sizeof(a));
+	g = geometry_for(d, n);
+	SieveArgs &a = grp.common;
 	a.bloom = d->d_sv_bloom;
 	a.bloom_log_words = d->sv_bloom_log_words;
 	a.bloom_words = 1u << d->sv_bloom_log_words;
@@ -1128,47 +1280,71 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	a.prefix_probes = d->sv_prefix_probes;
 	a.rec = (const uint4 *)d->d_sv_rec;
 	a.edges = (const uint4 *)d->d_sv_edges;
-	a.report_state = b->report == ACM_REPORT_STATE ? 1 : 0;
 	a.in_byte = d->d_in_byte;
 	a.cold = d->d_cold;
 	a.depth = d->d_depth;
-	a.out = b->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
+	a.out = d->d_out;
 	a.dev2ref = d->d_dev2ref;
 	a.F = d->first_final;
 	a.D = d->sv_prefix_len;
-	a.text16 = (const uint4 *)b->d_text;
-	a.text = (const uint8_t *)b->d_text;
 	a.n = (uint32_t)n;
 	a.n_pad = (uint32_t)((n + 15) & ~(size_t)15);
-	a.init_state = init_dev;
-	a.drop_before = (uint32_t)b->halo;
-	a.off_shift = (int32_t)b->offset_shift;
 	a.tile_bytes = g.tile_bytes;
 	a.ntiles = g.ntiles;
 	a.cap = g.cap;
-	char *ws = (char *)sparse_ws;
+	a.nrows = g.nrows;
+	a.scap = g.scap;
+	a.giveups = d->d_giveups;
 	size_t o = 0;
 	auto take = [&](size_t bytes) {
-		char *p = ws + o;
+		const size_t at = o;
 		o += align_up(bytes, 256);
-		return p;
+		return at;
 	};
-	a.summary = (uint32_t *)take((size_t)kMaxRows * kSummaryWords * 4);
-	a.lists = (uint2 *)take((size_t)g.nrows * g.cap * 8);
-	a.nrows = g.nrows;
-	a.samples = (uint2 *)take((size_t)g.ntiles * g.scap * 8);
-	a.shead = (uint2 *)take((size_t)g.ntiles * kSampleHead * 8);
-	a.lhead = (uint2 *)take((size_t)(g.nrows + kRowsPerThread) * kHitHead * 8);
-	a.scount = (uint32_t *)take((size_t)g.ntiles * 4);
-	a.scap = g.scap;
-	a.misc = (uint32_t *)take(256);
-	a.pat_plane = b->d_pat_plane;
-	a.off_plane = b->d_off_plane;
-	a.plane_capacity = (uint32_t)(b->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : b->plane_capacity);
-	a.path_marker = path_marker;
-	a.giveups = d->d_giveups;
+	grp.o_summary = take((size_t)kMaxRows * kSummaryWords * 4);
+	grp.o_lists = take((size_t)g.nrows * g.cap * 8);
+	grp.o_samples = take((size_t)g.ntiles * g.scap * 8);
+	grp.o_shead = take((size_t)g.ntiles * kSampleHead * 8);
+	grp.o_lhead = take((size_t)(g.nrows + kRowsPerThread) * kHitHead * 8);
+	grp.o_scount = take((size_t)g.ntiles * 4);
+	grp.o_misc = take(256);
+}
+
+void fill_batch(const SieveJob &job, SieveBatch &b)
+{
+	const acm_scan_batch *in = job.batch;
+	b.text = (const uint8_t *)in->d_text;
+	b.ws = (char *)job.sparse_ws;
+	b.pat_plane = in->d_pat_plane;
+	b.off_plane = in->d_off_plane;
+	b.path_marker = job.path_marker;
+	b.init_state = job.init_dev;
+	b.drop_before = (uint32_t)in->halo;
+	b.off_shift = (int32_t)in->offset_shift;
+	b.plane_capacity = (uint32_t)(in->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : in->plane_capacity);
+	b.report_state = in->report == ACM_REPORT_STATE ? 1 : 0;
+}
+}  // namespace
+
+int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count, hipStream_t s, hipEvent_t after_sieve,
+    hipEvent_t after_emit)
+{
+	if (count == 0 || count > kMaxGroup)
+		return acm::fail(ACM_ERR_ARG, "sparse_group_enqueue: %u batches", count);
+	for (uint32_t i = 1; i < count; i++)
+		if (jobs[i].batch->n != jobs[0].batch->n)
+			return acm::fail(ACM_ERR_ARG, "sparse_group_enqueue: the batches of a group must have one size");
+	const size_t n = jobs[0].batch->n;
+	SieveGroup grp;
+	memset(&grp, 0, sizeof(grp));
+	grp.count = count;
+	Geometry g;
+	fill_common(d, n, grp, g);
+	for (uint32_t i = 0; i < kMaxGroup; i++)   // (the bulk kernel reads all four: the spare ones repeat the last)
+		fill_batch(jobs[i < count ? i : count - 1], grp.b[i]);
+	SieveArgs &a = grp.common;
 	static unsigned long long *d_stamps = nullptr;
-	const bool want_stamps = getenv("ACM_SIEVE_STAMPS") != nullptr;
+	const bool want_stamps = count == 1 && getenv("ACM_SIEVE_STAMPS") != nullptr;
 	const size_t stamp_words = (size_t)(9000 + 128) * 8;
 	if (want_stamps) {
 		if (!d_stamps)
@@ -1194,28 +1370,28 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 		eblocks *= 2;
 	if (!want_stamps) {
 		switch (d->sv_stride) {
-		case 8: hipLaunchKernelGGL((k_sieve<8, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		case 4: hipLaunchKernelGGL((k_sieve<4, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		case 2: hipLaunchKernelGGL((k_sieve<2, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		default: hipLaunchKernelGGL((k_sieve<1, false>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 8: hipLaunchKernelGGL((k_sieve<8, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 4: hipLaunchKernelGGL((k_sieve<4, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		default: hipLaunchKernelGGL((k_sieve<1, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
 		}
 	} else {   // debugging aid: the same kernel with clock stamps
 		switch (d->sv_stride) {
-		case 8: hipLaunchKernelGGL((k_sieve<8, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		case 4: hipLaunchKernelGGL((k_sieve<4, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		case 2: hipLaunchKernelGGL((k_sieve<2, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
-		default: hipLaunchKernelGGL((k_sieve<1, true>), dim3(blocks), dim3(kBlock), lds, s, a); break;
+		case 8: hipLaunchKernelGGL((k_sieve<8, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 4: hipLaunchKernelGGL((k_sieve<4, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		default: hipLaunchKernelGGL((k_sieve<1, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
 		}
 	}
 	if (after_sieve)
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
 	switch (d->sv_stride) {
-	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
-	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
-	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
-	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks), dim3(kCheckBlock), 0, s, a); break;
+	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
+	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
+	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
+	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
 	}
-	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks), dim3(kEmitBlock), 0, s, a);
+	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
 	if (after_emit)
 		ACM_HIP_TRY(hipEventRecord(after_emit, s));
 	if (want_stamps) {   // debugging aid: where the waves spend their time (100 MHz clock)
@@ -1278,5 +1454,18 @@ int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }
+
+int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
+    uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit)
+{
+	SieveJob job;
+	job.batch = b;
+	job.init_dev = init_dev;
+	job.sparse_ws = sparse_ws;
+	job.path_marker = path_marker;
+	return sparse_group_enqueue(d, &job, 1, s, after_sieve, after_emit);
+}
+
+uint32_t sparse_max_group() { return kMaxGroup; }
 
 }  // namespace acm

@@ -218,11 +218,23 @@ int acm_expand_matches_async(const acm_dfa *, const int32_t *d_state_plane,
 
 int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
 
-/* count batches with one call, enqueued in array order, each on its own
- * stream: what a worker pool issues per round, without a trip through the
- * FFI per batch.  Stops at the first batch that fails and returns its status
- * (the batches before it stay enqueued). */
+/* count batches with one call, enqueued in array order: what a worker pool
+ * issues per round, without a trip through the FFI per batch.  Stops at the
+ * first batch that fails and returns its status (the batches before it stay
+ * enqueued).
+ *
+ * Grouping: consecutive batches that take the sparse pipeline, have the same
+ * stream and size, each its OWN workspace and planes, no events and no
+ * profiling, are enqueued up to acm_scan_set_max_group() at a time as ONE set
+ * of three launches -- the kernels' fixed costs (launch, filter fill, the
+ * check kernel's chains of dependent loads) are paid per group instead of per
+ * batch.  Results are those of enqueueing the batches one by one; they become
+ * visible in stream order when the group's last kernel has run.  Batches that
+ * share a workspace are never grouped. */
 int acm_scan_batches_async(const acm_dfa *, const acm_scan_batch *batches, size_t count);
+/* batches per group, 1 (never group) .. 4 (default).  Returns the value in use;
+ * 0 or negative only queries. */
+int acm_scan_set_max_group(acm_dfa *, int batches);
 
 /* independent chains each lane interleaves in the walk kernel: 2 or 4.
  * Returns the value in use. */

@@ -4,11 +4,14 @@ bit, whichever pipeline produced them -- including texts that are all matches or
 trie path, which the sparse pipeline handles itself (slowly) and AUTO mode learns to hand to the
 chain pipeline.
 """
+import os
+
 import numpy as np
 import pytest
 
 import fixtures
 import orc
+import synth
 from gpu_pattern_matching_amd import Automaton, DeviceArray, Matcher
 
 pytestmark = pytest.mark.gpu
@@ -395,3 +398,59 @@ def test_real_binary_content(gpu):
         assert set(paths) <= {"sparse", "chain"}
         print(name, os.path.basename(libs[-1]), paths)
         m.close()
+
+
+def _planes(pat, off, cap, stream=None):
+    p, o = pat.to_numpy(np.int32, cap, stream=stream), off.to_numpy(np.int32, cap, stream=stream)
+    m = int(p[0])
+    return o[1:1 + m].astype(np.uint32), p[1:1 + m].copy(), int(p[m + 1])
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 4])
+def test_grouped_batches(gpu, group):
+    """acm_scan_batches_async puts consecutive sparse batches of one size into one set of launches:
+    the planes of every batch are those of scanning it alone -- different texts, different carried-in
+    states, halos; batches that share a workspace, differ in size or take the chain pipeline are
+    enqueued on their own, in order."""
+    pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 400)
+    a, o = build(pats)
+    n = (1 << 20) + 40
+    m = Matcher(a, 0, max_text=n)
+    assert m.set_mode("sparse") == "sparse"
+    assert m.set_max_group(group) == group
+    rng = np.random.default_rng(group)
+    nb = 7
+    texts, inits = [], []
+    for k in range(nb):
+        t = rng.integers(0, 256, size=n, dtype=np.uint8)
+        for _ in range(300):
+            p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+            at = int(rng.integers(0, n - p.size))
+            t[at:at + p.size] = p
+        if k % 3 == 1:   # a signature that began in the previous buffer
+            p = np.frombuffer(pats[k], dtype=np.uint8)
+            t[:p.size - 5] = p[5:]
+            inits.append(o.scan(p[:5].tobytes())[2])
+        else:
+            inits.append(0)
+        texts.append(t)
+    ws_bytes = m.lib.acm_scan_workspace_bytes(m.dfa, n)
+    cap = 1 << 14
+    d_texts = [DeviceArray.from_numpy(t) for t in texts]
+    wss = [DeviceArray(ws_bytes) for _ in range(nb)]
+    planes = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(nb)]
+    sizes = [n, n, n, n - 16, n, n, n]                   # batch 3 breaks the run
+    ws_of = [0, 1, 2, 3, 4, 4, 5]                        # 4 and 5 share a workspace: never together
+    batches = [m.make_batch(d_texts[k], sizes[k], m.stream, planes[k][0], planes[k][1], cap, (wss[ws_of[k]], ws_bytes),
+                            init_state=inits[k], halo=(64 if k == 2 else 0), offset_shift=(1000 if k == 2 else 0))
+               for k in range(nb)]
+    for rep in range(2):
+        m.enqueue_many(batches)
+        for k in range(nb):
+            got = _planes(planes[k][0], planes[k][1], cap, m.stream)
+            epos, epat, elast = o.scan(texts[k][:sizes[k]], init_state=inits[k])
+            if k == 2:
+                keep = epos >= 64
+                epos, epat = epos[keep] + 1000, epat[keep]
+            assert_same(got, (epos, epat, elast))
+    m.close()
