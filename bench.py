@@ -224,7 +224,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         return out
 
     plain, profiled = batches(False), batches(True)
-    native = args.issue == "native"
+    native = args.issue == "native" or (args.issue == "threads" and W == 1)   # one worker: the caller is the thread
     pool = Pool(W) if (W > 1 and args.issue == "threads") else None
     enq, enq_many = matcher.lib.acm_scan_batch_async, matcher.lib.acm_scan_batches_async
     dfa = matcher.dfa

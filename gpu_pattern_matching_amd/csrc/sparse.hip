@@ -42,7 +42,7 @@
 // state after the last D-1 bytes from the root (depth < D there).
 //
 // Three launches, no host round trip between them:
-//   k_sieve        the bulk pass.  One workgroup of 16 waves per CU with the Bloom filter
+//   k_sieve        the bulk pass.  One workgroup of 8 waves per CU with the Bloom filter
 //                  in LDS; a wave owns a tile of the text at a time: reads it 16 B per
 //                  lane, probes one 3-gram per W bytes, appends {position, 3-gram} of what
 //                  the filter flags to the tile's sample list (ranks from ballots).
@@ -80,7 +80,7 @@ namespace {
 
 using acm_dev::agree16;
 
-constexpr int kBlock = 1024;               // threads of a k_sieve workgroup
+constexpr int kBlock = 512;              // threads of a k_sieve workgroup
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kTilesPerChecker = 8;   // tiles whose flagged samples one wave of k_sieve_check takes
 constexpr int kCheckBlock = 64;            // threads of a k_sieve_check workgroup
@@ -1353,11 +1353,13 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		a.stamps = d_stamps;
 	}
 
-	// K1: persistent workgroups of 16 waves, a tile per wave at a time, ONE workgroup per CU (it asks
-	// for more than half of the LDS whatever the filter's size): 16 waves with 8 KiB in flight each
-	// saturate the memory system, and the other half of the CU's wave slots stays free for the check
-	// and emit kernels of the batches in flight on other streams -- with two bulk kernels resident
-	// everywhere those would wait for a whole bulk workgroup to drain, every time.
+	// K1: persistent workgroups of 8 waves, a tile per wave at a time, ONE workgroup per CU (it asks
+	// for more than half of the LDS whatever the filter's size): 8 waves with 8 KiB in flight each
+	// keep the memory system as busy as 16 do (measured: 16 are 1 us slower per launch, 4 are 3 us
+	// slower; a second register set prefetching the wave's next tile gains nothing either), and
+	// three quarters of the CU's wave slots and registers stay free for the check and emit kernels
+	// of the batches in flight on other streams -- with two bulk kernels resident everywhere those
+	// would wait for a whole bulk workgroup to drain, every time.
 	const size_t lds = std::max((size_t)a.bloom_words * 4, (size_t)84 * 1024);
 	uint32_t blocks = (g.ntiles + kWaves - 1) / kWaves;
 	if (blocks > (uint32_t)d->num_cus)
