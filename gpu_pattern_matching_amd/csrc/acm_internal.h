@@ -27,22 +27,10 @@ void clear_error();
 // ---- design limits --------------------------------------------------------
 constexpr uint32_t kMaxStates = 1u << 24;     // state id packed in 24 bits of a staged record
 constexpr int kMaxPatternLine = 4096;         // utils.h:14 MAX_PAT_SIZE
-constexpr uint32_t kHotRowsMax = 256;         // rows staged in LDS (256 * 512 B = 128 KiB)
+constexpr uint32_t kHotRowsMax = 256;         // rows of 256 cells staged in LDS (256 * 512 B = 128 KiB); more with byte classes
+constexpr uint32_t kHotBytes = kHotRowsMax * 512;
 constexpr uint32_t kHotSentinel = 0xFFFFu;    // hot cell value meaning "look in the cold plane"
 constexpr uint32_t kNoPattern = 0xFFFFFFFFu;
-
-// trigram filter of the sparse pipeline (sparse.hip): a blocked Bloom filter,
-// both bits of a key in one 32-bit word; 2^10 .. 2^15 words (4 .. 128 KiB of
-// LDS), sized at upload to about 4 words per key
-constexpr uint32_t kBloomMinLogWords = 10, kBloomMaxLogWords = 15;
-constexpr uint32_t kBloomMaxWords = 1u << kBloomMaxLogWords;
-constexpr uint32_t kBloomMul1 = 0x9E3779u, kBloomMul2 = 0x85EBCAu;   // 24-bit odd multipliers
-inline uint32_t bloom_word(uint32_t tri, uint32_t log_words) { return (uint32_t)(tri * kBloomMul1) >> (32 - log_words); }
-inline uint32_t bloom_bits(uint32_t tri)
-{
-	const uint32_t p = (uint32_t)(tri * kBloomMul2);
-	return (1u << (p >> 27)) | (1u << ((p >> 22) & 31));
-}
 
 }  // namespace acm
 
@@ -84,6 +72,15 @@ struct acm_automaton {
 	std::vector<int32_t> list_begin;       // [ref] offset into list_pool or -1
 	std::vector<int32_t> list_len;         // [ref]
 	std::vector<int32_t> list_pool;
+
+	// Byte classes: bytes that occur in no pattern all lead to the root from every state, so
+	// they share one column of the DFA (class 0); every other byte has a class of its own.  A
+	// set over a small alphabet (26 letters -> 27 classes) has rows of 32 cells instead of 256:
+	// eight times as many states fit the LDS rows, and the planes of the chain pipeline shrink
+	// to L2 size.  log_stride = 8: no compression (every byte its own class, identity map).
+	uint8_t byte_class[256];
+	uint8_t class_byte[256];               // a byte of each class
+	uint32_t num_classes = 256, log_stride = 8;
 
 	std::vector<uint32_t> ref2dev, dev2ref;
 	uint32_t hot_count = 0;                // dev ids below this are the LDS rows

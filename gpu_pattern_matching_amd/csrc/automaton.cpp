@@ -332,15 +332,50 @@ struct Builder {
 	// the other non-final states and the final states, both in ref order.
 	// The root is never final: a transition into state 0 cannot be flagged
 	// because the reference stores finals as -state (acsmx.c:645).
+	void byte_classes()
+	{
+		bool used[256] = { false };
+		for (const auto &p : a.patterns)
+			for (uint8_t b : p.bytes)
+				used[b] = true;
+		uint32_t nused = 0;
+		for (int b = 0; b < 256; b++)
+			nused += used[b] ? 1 : 0;
+		const uint32_t classes = nused + (nused < 256 ? 1 : 0);
+		if (classes > 128) {   // nothing to gain: the identity
+			for (int b = 0; b < 256; b++)
+				a.byte_class[b] = a.class_byte[b] = (uint8_t)b;
+			a.num_classes = 256;
+			a.log_stride = 8;
+			return;
+		}
+		uint32_t next = 1, spare = 0;
+		for (int b = 0; b < 256; b++)
+			if (!used[b])
+				spare = (uint32_t)b;   // (one exists: fewer than 256 bytes are used)
+		memset(a.class_byte, (int)spare, sizeof(a.class_byte));
+		for (int b = 0; b < 256; b++) {
+			a.byte_class[b] = used[b] ? (uint8_t)next : 0;
+			if (used[b])
+				a.class_byte[next++] = (uint8_t)b;
+		}
+		a.num_classes = classes;
+		a.log_stride = 1;
+		while ((1u << a.log_stride) < classes)
+			a.log_stride++;
+	}
+
 	void number_for_device()
 	{
 		const uint32_t n = a.num_states;
+		// rows the LDS budget of the walk kernel holds (a hot cell is 16 bits: ids below the sentinel)
+		const uint32_t hot_max = std::min<uint32_t>(acm::kHotBytes / (2u << a.log_stride), 0x8000u);
 		a.ref2dev.assign(n, UINT32_MAX);
 		a.dev2ref.assign(n, 0);
 		uint32_t next = 0;
 		a.hot_depth1 = 0;
 		for (uint32_t s : a.bfs_order) {
-			if (next >= acm::kHotRowsMax)
+			if (next >= hot_max)
 				break;
 			if (a.is_final_ref(s))
 				continue;
@@ -429,6 +464,7 @@ extern "C" int acm_automaton_compile(acm_automaton *a)
 		b.insert_patterns();
 		b.index_children();
 		b.link_and_collect();
+		b.byte_classes();
 		b.number_for_device();
 		b.chain_patterns();
 		b.unary_runs();

@@ -1,7 +1,7 @@
 // Device helpers shared by the chain pipeline (scan.hip) and the sparse
 // pipeline (sparse.hip): exact DFA walking over the deep plane with
 // fast-forward along unary trie paths.  'A' is any kernel-argument struct
-// with members deep, in_byte, text, text16, n_pad.
+// with members deep, ls, cls, in_byte, text, text16, n_pad.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -45,7 +45,9 @@ struct Deep {
 template <class A>
 __device__ __forceinline__ Deep deep_step(const A &a, uint32_t state, uint32_t byte)
 {
-	const size_t idx = ((size_t)state << 8) | byte;
+	// (rows have one cell per byte class; the class map is 256 bytes that never leave the L1)
+	const uint32_t col = a.ls == 8 ? byte : (uint32_t)a.cls[byte];
+	const size_t idx = ((size_t)state << a.ls) | col;
 	const uint64_t cell = a.deep[idx];   // target | depth << 32 | run << 48: one load, one TLB entry
 	const uint32_t next = (uint32_t)cell, m = (uint32_t)(cell >> 32);
 	Deep d;

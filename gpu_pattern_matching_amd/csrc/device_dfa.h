@@ -17,9 +17,11 @@ struct acm_dfa {
 	uint32_t hot_depth1 = 1;             // hot ids below this have depth <= 1
 	uint32_t max_pattern_len = 0;
 
-	uint32_t *d_cold = nullptr;          // [states][256] target id
-	uint64_t *d_deep = nullptr;          // [states][256] target id | depth(target) << 32 | run(target) << 48
-	uint16_t *d_hot = nullptr;           // [hot_rows][256]
+	uint32_t log_stride = 8;             // cells per row of the planes below = 1 << log_stride (byte classes; 8: bytes)
+	uint8_t *d_class = nullptr;          // [256] byte -> class (the identity when log_stride == 8)
+	uint32_t *d_cold = nullptr;          // [states][stride] target id
+	uint64_t *d_deep = nullptr;          // [states][stride] target id | depth(target) << 32 | run(target) << 48
+	uint16_t *d_hot = nullptr;           // [hot_rows][stride]
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
 	uint8_t *d_in_byte = nullptr;        // [states + 224] byte on the edge into dev state
@@ -73,6 +75,7 @@ struct acm_dfa {
 		uint64_t last_use;
 	};
 	static constexpr size_t kMaxGraphs = 32;
+	bool use_halo = true;                // chain pipeline: halo mode where the longest pattern fits a chain (scan.hip)
 	int max_group = 4;                   // batches acm_scan_batches_async puts into one set of sparse launches
 	mutable bool use_graphs = false;     // opt-in: measured neutral on this stack
 	mutable std::vector<GraphEntry> graphs;

@@ -264,9 +264,20 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		const std::vector<uint64_t> &rows = a->dense_rows();
 		const uint32_t n = a->num_states, H = a->hot_count, F = a->first_final;
 
-		std::vector<uint16_t> hot((size_t)H * 256);
-		for (size_t i = 0; i < hot.size(); i++) {
-			const uint32_t t = (uint32_t)rows[i];
+		// the planes of the chain pipeline, one column per byte class (automaton: byte_classes)
+		const uint32_t ls = a->log_stride, stride = 1u << ls;
+		d->log_stride = ls;
+		std::vector<uint64_t> packed;
+		if (ls != 8) {
+			packed.assign((size_t)n << ls, 0);
+			for (uint32_t s = 0; s < n; s++)
+				for (uint32_t c = 0; c < stride; c++)
+					packed[((size_t)s << ls) | c] = rows[((size_t)s << 8) | a->class_byte[c]];
+		}
+		const std::vector<uint64_t> &cells = ls != 8 ? packed : rows;
+		std::vector<uint16_t> hot((((size_t)H << ls) + 7) & ~(size_t)7, (uint16_t)acm::kHotSentinel);   // whole uint4s
+		for (size_t i = 0; i < ((size_t)H << ls); i++) {
+			const uint32_t t = (uint32_t)cells[i];
 			hot[i] = (uint16_t)((t < acm::kHotSentinel && t < F) ? t : acm::kHotSentinel);
 		}
 		std::vector<int32_t> outp(n);
@@ -277,12 +288,14 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 			inb[s] = a->in_byte[r];
 		}
 		{
-			std::vector<uint32_t> plane(rows.size());
-			for (size_t i = 0; i < rows.size(); i++)
-				plane[i] = (uint32_t)rows[i];
+			std::vector<uint32_t> plane(cells.size());
+			for (size_t i = 0; i < cells.size(); i++)
+				plane[i] = (uint32_t)cells[i];
 			rc = upload(&d->d_cold, plane.data(), plane.size(), &d->device_bytes);
 			if (rc == ACM_OK)
-				rc = upload(&d->d_deep, rows.data(), rows.size(), &d->device_bytes);
+				rc = upload(&d->d_deep, cells.data(), cells.size(), &d->device_bytes);
+			if (rc == ACM_OK)
+				rc = upload_small(d, &d->d_class, (const uint8_t *)a->byte_class, (size_t)256);
 		}
 		if (rc == ACM_OK) rc = upload(&d->d_hot, hot.data(), hot.size(), &d->device_bytes);
 		if (rc == ACM_OK) rc = upload_small(d, &d->d_out, outp.data(), outp.size());
@@ -333,6 +346,8 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		if (!strcmp(m, "chain")) d->scan_mode = ACM_SCAN_MODE_CHAIN;
 		else if (!strcmp(m, "sparse")) d->scan_mode = ACM_SCAN_MODE_SPARSE;
 	}
+	if (const char *h = getenv("ACM_SCAN_HALO"))   // debugging aid: 0 = always speculate and resolve
+		d->use_halo = atoi(h) != 0;
 	if (const char *g = getenv("ACM_SCAN_GRAPHS"))
 		d->use_graphs = atoi(g) != 0;
 	hipDeviceProp_t prop;
@@ -357,6 +372,7 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		hipFree(d->d_list_len);
 		hipFree(d->d_list_pool);
 		free_small(d, d->d_depth);
+		free_small(d, d->d_class);
 		free_small(d, d->d_sv_bloom);
 		free_small(d, d->d_sv_gram);
 		free_small(d, d->d_sv_prefix);

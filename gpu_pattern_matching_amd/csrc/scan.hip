@@ -71,9 +71,13 @@ constexpr uint32_t kNoFirst = 0xFFFFu;
 constexpr uint8_t kProbeTodo = 0xFF;
 
 struct ScanArgs {
-	const uint32_t *cold;   // [states][256] next state
-	const uint64_t *deep;   // [states][256] next | depth(next) << 32 | run(next) << 48
-	const uint16_t *hot;
+	const uint32_t *cold;   // [states][1 << ls] next state, a cell per byte class
+	const uint64_t *deep;   // [states][1 << ls] next | depth(next) << 32 | run(next) << 48
+	const uint16_t *hot;    // [H][1 << ls]
+	const uint8_t *cls;     // [256] byte -> class (the identity when ls == 8)
+	uint32_t ls;            // log2 of the cells per row
+	uint32_t halo_bytes;    // halo mode (below, walk_tile): bytes every chain walks in front of its own; else 0
+	uint32_t halo_mode;
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	const uint8_t *in_byte;
@@ -140,17 +144,19 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &w)
 // branch around that is wave-uniform.  (Issuing the HBM gather before the LDS
 // result is known -- the plane a lane needs only depends on its state --
 // measured 35% SLOWER on MI355X, so the gather waits for the LDS cell.)
-template <int C, int K, bool GUARD>
-__device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot, const uint4 (&w)[C],
+template <int C, int K, bool GUARD, bool CLS, bool HALO>
+__device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot, const uint8_t *clsmap, uint32_t ls,
+    const uint4 (&w)[C],
     uint32_t (&st)[C], uint32_t (&cnt)[C], uint32_t (&first)[C], const uint32_t (&base)[C],
-    const uint32_t (&len)[C], uint32_t g, uint32_t &wcount, uint2 *stage)
+    const uint32_t (&len)[C], const uint32_t (&lead)[C], uint32_t hb, uint32_t g, uint32_t &wcount, uint2 *stage)
 {
 	uint32_t idx[C], e[C];
 	bool need[C];
 	bool any_need = false;
 #pragma unroll
 	for (int c = 0; c < C; c++) {
-		idx[c] = (st[c] << 8) | byte_of<K>(w[c]);
+		const uint32_t b = byte_of<K>(w[c]);
+		idx[c] = CLS ? (st[c] << ls) | clsmap[b] : (st[c] << 8) | b;   // (the class of a byte: one more LDS read, off the chain)
 		e[c] = hot[st[c] < a.H ? idx[c] : 0u];
 	}
 #pragma unroll
@@ -167,27 +173,29 @@ __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot,
 		for (int c = 0; c < C; c++)
 			e[c] = need[c] ? v[c] : e[c];
 	}
-	const uint32_t step = g * 16 + K + 1;  // 1-based step inside the chain
+	// 1-based step inside the chain; in halo mode the first hb bytes of the walk lie in front of
+	// the chain (steps <= 0): they only bring the state up to date
+	const int32_t step = (int32_t)(g * 16 + K + 1) - (HALO ? (int32_t)hb : 0);
 	bool hit[C];
 	bool any_hit = false;
 #pragma unroll
 	for (int c = 0; c < C; c++) {
-		if (GUARD && step > len[c])
-			e[c] = st[c];  // past the end of the text: freeze
-		hit[c] = (e[c] >= a.F) && (!GUARD || step <= len[c]);
+		if (GUARD && (step > (int32_t)len[c] || (HALO && step <= -(int32_t)lead[c])))
+			e[c] = st[c];  // past the end of the text, or in front of where this chain's walk starts: freeze
+		hit[c] = (e[c] >= a.F) && (!HALO || step >= 1) && (!GUARD || step <= (int32_t)len[c]);
 		any_hit |= hit[c];
 	}
 	if (__builtin_amdgcn_ballot_w64(any_hit)) {
 #pragma unroll
 		for (int c = 0; c < C; c++) {
-			hit[c] = hit[c] && (base[c] + step - 1 >= a.drop_before);
+			hit[c] = hit[c] && (base[c] + (uint32_t)step - 1 >= a.drop_before);
 			const uint64_t m = __builtin_amdgcn_ballot_w64(hit[c]);
 			if (m) {
 				if (hit[c]) {
 					stage[wcount + mbcnt64(m)] =
-					    make_uint2(base[c] + step - 1, e[c] | (cnt[c] << 24));
+					    make_uint2(base[c] + (uint32_t)step - 1, e[c] | (cnt[c] << 24));
 					if (cnt[c] == 0)
-						first[c] = step;
+						first[c] = (uint32_t)step;
 					cnt[c]++;
 				}
 				wcount += (uint32_t)__popcll(m);
@@ -208,7 +216,7 @@ __device__ __forceinline__ void step_all(const ScanArgs &a, const uint16_t *hot,
 // is made of such chains, is final: count = K1 count, nothing to re-walk.
 // Everything else is left to k_probe / k_resolve through the flag arrays.
 template <int C>
-__device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t *hot, uint32_t wt,
+__device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t *hot, uint32_t ls, uint32_t wt,
     uint32_t lane, const uint32_t (&st)[C], const uint32_t (&cnt)[C], const uint32_t (&chain)[C],
     const uint32_t (&fb)[C])
 {
@@ -234,7 +242,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 			if (pe == 0) {
 				ok = true;
 			} else if (pe < a.H) {
-				const uint32_t t = hot[(pe << 8) | fb[c]];
+				const uint32_t t = hot[(pe << ls) | fb[c]];   // fb: the class of the chain's first byte
 				ok = t < a.hot_depth1;   // non-final, depth <= 1 (a sentinel cell is never below)
 			}
 		}
@@ -273,11 +281,20 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 	}
 }
 
-template <int C, bool GUARD>
-__device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot, uint32_t wt,
+// Halo mode (HALO): when the longest pattern is short against the chain (L - 1 <= S, a set of
+// words), a chain does not start in the root at its first byte and leave the truth to the probe
+// and resolve kernels -- it starts hb = L - 1 bytes (rounded up to 16) EARLIER: the DFA state only
+// remembers the last L - 1 bytes, so from its own first byte on the walk is the serial one.  Hits
+// in front of the chain are not counted; the chain's count is final, the tile's total goes to the
+// scatter kernel directly, k_probe and k_resolve are not launched.  A chain less than hb bytes
+// into the text starts at byte 0 in the carried-in state.
+template <int C, bool GUARD, bool CLS, bool HALO>
+__device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot, const uint8_t *clsmap, uint32_t wt,
     uint32_t lane)
 {
-	uint32_t st[C], cnt[C], first[C], base[C], len[C], chain[C], fb[C];
+	const uint32_t ls = CLS ? a.ls : 8u;
+	const uint32_t hb = HALO ? a.halo_bytes : 0u;
+	uint32_t st[C], cnt[C], first[C], base[C], len[C], chain[C], fb[C], lead[C];
 	uint32_t wcount = 0;
 	uint2 *stage = a.stage1 + (((size_t)wt * C * 64) << a.logS);
 #pragma unroll
@@ -285,31 +302,57 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 		chain[c] = (wt * C + c) * 64 + lane;
 		base[c] = chain[c] << a.logS;
 		len[c] = GUARD ? (base[c] >= a.n ? 0u : min(a.S, a.n - base[c])) : a.S;
-		st[c] = 0;
+		lead[c] = min(hb, base[c]);
+		st[c] = (HALO && base[c] <= hb) ? a.init_state : 0u;
 		cnt[c] = 0;
 		first[c] = kNoFirst;
 		fb[c] = 0;
 	}
-	const uint32_t groups = a.S >> 4;
+	const uint32_t groups = (a.S + hb) >> 4;
 	for (uint32_t g = 0; g < groups; g++) {
 		// (prefetching the next group does not help: vector loads return in order, so
 		// the first cold gather of this group would wait for the prefetch anyway)
 		uint4 w[C];
 #pragma unroll
 		for (int c = 0; c < C; c++) {
-			if (!GUARD || base[c] + g * 16 < a.n)
-				w[c] = a.text16[(base[c] >> 4) + g];
+			const int64_t at = (int64_t)base[c] - hb + (int64_t)g * 16;   // first byte of the group
+			if (!GUARD || (at >= 0 && at < (int64_t)a.n))
+				w[c] = a.text16[at >> 4];
 			else
 				w[c] = make_uint4(0, 0, 0, 0);
-			if (g == 0)
-				fb[c] = w[c].x & 0xFFu;
+			if (!HALO && g == 0)
+				fb[c] = CLS ? (uint32_t)clsmap[w[c].x & 0xFFu] : w[c].x & 0xFFu;
 		}
-#define ACM_STEP(K) step_all<C, K, GUARD>(a, hot, w, st, cnt, first, base, len, g, wcount, stage)
+#define ACM_STEP(K) step_all<C, K, GUARD, CLS, HALO>(a, hot, clsmap, ls, w, st, cnt, first, base, len, lead, hb, g, wcount, stage)
 		ACM_STEP(0); ACM_STEP(1); ACM_STEP(2); ACM_STEP(3);
 		ACM_STEP(4); ACM_STEP(5); ACM_STEP(6); ACM_STEP(7);
 		ACM_STEP(8); ACM_STEP(9); ACM_STEP(10); ACM_STEP(11);
 		ACM_STEP(12); ACM_STEP(13); ACM_STEP(14); ACM_STEP(15);
 #undef ACM_STEP
+	}
+	if (HALO) {
+		static_assert(!HALO || C * 64 == kBlock2, "halo mode: a wave tile is a scatter block");
+		uint32_t total = 0;
+#pragma unroll
+		for (int c = 0; c < C; c++) {
+			if (chain[c] < a.n_chains) {
+				a.cnt[chain[c]] = (int32_t)cnt[c];
+				a.k2info[chain[c]] = 0;
+				total += cnt[c];
+				if (chain[c] == a.n_chains - 1)
+					a.misc[0] = st[c];   // the state after the last byte
+			}
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			total += __shfl_xor(total, o, 64);
+		if (lane == 0) {
+			a.wave_cnt1[wt] = wcount;
+			a.off[wt] = (int32_t)total;   // the scatter block's total (k_resolve's job otherwise)
+		}
+		if (lane < kBlock2 / 64)
+			a.wave_cnt2[wt * (kBlock2 / 64) + lane] = 0;   // nothing staged by a resolve kernel
+		return;
 	}
 #pragma unroll
 	for (int c = 0; c < C; c++) {
@@ -320,21 +363,24 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 	}
 	if (lane == 0)
 		a.wave_cnt1[wt] = wcount;
-	tile_epilogue<C>(a, hot, wt, lane, st, cnt, chain, fb);
+	tile_epilogue<C>(a, hot, ls, wt, lane, st, cnt, chain, fb);
 }
 
 // K1: persistent workgroups (one per CU), the hot rows live in LDS for the
 // whole launch, each wave takes wave tiles of C*64 chains round-robin.
-template <int C>
+template <int C, bool CLS, bool HALO>
 __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
+	uint8_t *clsmap = (uint8_t *)hot + acm::kHotBytes;   // behind the rows: the byte classes (CLS only)
+	if (CLS && threadIdx.x < 64)
+		((uint32_t *)clsmap)[threadIdx.x] = ((const uint32_t *)a.cls)[threadIdx.x];
 	{
 		// every workgroup copies the same table: start each one at a different
 		// offset so the CUs do not all ask the same L2 channel at the same time
 		const uint4 *src = (const uint4 *)a.hot;
 		uint4 *dst = (uint4 *)hot;
-		const uint32_t n16 = a.H * 32;  // 512 B per row
+		const uint32_t n16 = ((a.H << a.ls) + 7) >> 3;  // uint4s: a row has 1 << ls cells of 2 bytes (the table is padded to 16)
 		const uint32_t rot = n16 ? (blockIdx.x * 1021u) % n16 : 0u;
 		for (uint32_t i = threadIdx.x; i < n16; i += kBlock1) {
 			uint32_t j = i + rot;
@@ -348,11 +394,12 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 	const uint32_t nwaves = gridDim.x * kWaves1;
 	const uint32_t tile_bytes = (C * 64u) << a.logS;
 	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
-		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n;
+		// (the unguarded walk: every chain of the tile whole, and in halo mode with its whole halo)
+		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n && (!HALO || (uint64_t)wt * tile_bytes >= a.halo_bytes);
 		if (full)
-			walk_tile<C, false>(a, hot, wt, lane);
+			walk_tile<C, false, CLS, HALO>(a, hot, clsmap, wt, lane);
 		else
-			walk_tile<C, true>(a, hot, wt, lane);
+			walk_tile<C, true, CLS, HALO>(a, hot, clsmap, wt, lane);
 	}
 }
 
@@ -742,11 +789,20 @@ Layout layout_for(const acm_dfa *d, size_t max_text)
 template <int C>
 int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 {
-	const size_t lds = (size_t)a.H * 512;   // above 48 KiB: allowed by acm::scan_prepare
+	const size_t lds = acm::kHotBytes + 256;   // rows + class map; above 48 KiB: allowed by acm::scan_prepare
 	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
 	if (blocks > (uint32_t)num_cus)
 		blocks = (uint32_t)num_cus;
-	hipLaunchKernelGGL(k_spec_walk<C>, dim3(blocks), dim3(kBlock1), lds, s, a);
+	if (a.halo_mode && C == 4) {
+		if (a.ls == 8)
+			hipLaunchKernelGGL((k_spec_walk<4, false, true>), dim3(blocks), dim3(kBlock1), lds, s, a);
+		else
+			hipLaunchKernelGGL((k_spec_walk<4, true, true>), dim3(blocks), dim3(kBlock1), lds, s, a);
+	} else if (a.ls == 8) {
+		hipLaunchKernelGGL((k_spec_walk<C, false, false>), dim3(blocks), dim3(kBlock1), lds, s, a);
+	} else {
+		hipLaunchKernelGGL((k_spec_walk<C, true, false>), dim3(blocks), dim3(kBlock1), lds, s, a);
+	}
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }
@@ -934,10 +990,11 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 namespace acm {
 int scan_prepare(const acm_dfa *)
 {
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_spec_walk<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-	    (int)(acm::kHotRowsMax * 512)));
-	ACM_HIP_TRY(hipFuncSetAttribute((const void *)k_spec_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-	    (int)(acm::kHotRowsMax * 512)));
+	const void *walks[] = { (const void *)k_spec_walk<4, false, false>, (const void *)k_spec_walk<4, true, false>,
+		(const void *)k_spec_walk<2, false, false>, (const void *)k_spec_walk<2, true, false>,
+		(const void *)k_spec_walk<4, false, true>, (const void *)k_spec_walk<4, true, true> };
+	for (const void *k : walks)
+		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(acm::kHotBytes + 256)));
 	return ACM_OK;
 }
 }  // namespace acm
@@ -1136,6 +1193,8 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 	a.cold = d->d_cold;
 	a.deep = d->d_deep;
 	a.hot = d->d_hot;
+	a.cls = d->d_class;
+	a.ls = d->log_stride;
 	// the plane value of a record is a per-state table lookup: the head pattern, or the state's
 	// reference id when the caller wants to expand the whole match list afterwards
 	a.out = batch->report == ACM_REPORT_STATE ? (const int32_t *)d->d_dev2ref : d->d_out;
@@ -1157,6 +1216,12 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 	if (a.q == 0)
 		a.q = 1;
 	a.init_state = d->ref2dev[(size_t)init_state];
+	{
+		// halo mode (walk_tile): the longest pattern fits the chain -- no speculation to resolve
+		const uint32_t hb = ((a.L > 1 ? a.L - 1 : 0u) + 15u) & ~15u;
+		a.halo_mode = (d->use_halo && C == 4 && hb <= S) ? 1u : 0u;
+		a.halo_bytes = a.halo_mode ? hb : 0u;
+	}
 	a.drop_before = (uint32_t)halo;
 	a.off_shift = (int32_t)offset_shift;
 	a.end_state = (uint32_t *)(ws + l.end_state);
@@ -1231,9 +1296,11 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 		ACM_HIP_TRY(hipEventRecord(ev[2], s));
 	}
 	const uint32_t nb = (a.n_chains + kBlock2 - 1) / kBlock2;   // K2 blocks == scatter blocks
-	hipLaunchKernelGGL(k_probe, dim3(nb), dim3(kBlock2), 0, s, a);
-	hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(kBlock2), 0, s, a);
-	ACM_HIP_TRY(hipGetLastError());
+	if (!a.halo_mode) {
+		hipLaunchKernelGGL(k_probe, dim3(nb), dim3(kBlock2), 0, s, a);
+		hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(kBlock2), 0, s, a);
+		ACM_HIP_TRY(hipGetLastError());
+	}
 	if (nb <= kFoldMax) {
 		a.fold_blocks = nb;   // the scatter kernel sums the block totals itself: one launch less
 	} else if (nb <= kTopMax) {

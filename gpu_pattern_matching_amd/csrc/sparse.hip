@@ -106,7 +106,9 @@ struct SieveArgs {
 	const uint4 *rec, *edges;
 	uint32_t report_state;        // planes get the final state's reference id instead of its pattern
 	const uint8_t *in_byte;
-	const uint32_t *cold;
+	const uint32_t *cold;         // [states][1 << ls]: the real DFA, a cell per byte class
+	const uint8_t *cls;           // [256] byte -> class
+	uint32_t ls;
 	const uint16_t *depth;
 	const int32_t *out;
 	const uint32_t *dev2ref;
@@ -656,7 +658,7 @@ __device__ void side_walks(const SieveArgs &a)
 	{
 		uint32_t st = 0;
 		for (uint32_t x = a.n > a.D - 1 ? a.n - (a.D - 1) : 0u; x < a.n; x++)
-			st = a.cold[((size_t)st << 8) | a.text[x]];
+			st = a.cold[((size_t)st << a.ls) | a.cls[a.text[x]]];
 		a.misc[0] = st;
 	}
 	Row t;
@@ -682,7 +684,7 @@ __device__ void side_walks(const SieveArgs &a)
 		}
 		const uint32_t c = a.text[x];
 		const uint4 rec = a.rec[state];
-		const uint32_t next = a.cold[((size_t)state << 8) | c];
+		const uint32_t next = a.cold[((size_t)state << a.ls) | a.cls[c]];
 		if ((uint32_t)a.depth[next] < x + 2)
 			break;   // the state after byte x starts at or behind byte 0: a follower's business
 		run = ((rec.y & 0x1FFu) == 1 && (rec.x & 0xFFFFFFu) == next) ? rec.y >> 16 : 0u;
@@ -1282,6 +1284,8 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.edges = (const uint4 *)d->d_sv_edges;
 	a.in_byte = d->d_in_byte;
 	a.cold = d->d_cold;
+	a.cls = d->d_class;
+	a.ls = d->log_stride;
 	a.depth = d->d_depth;
 	a.out = d->d_out;
 	a.dev2ref = d->d_dev2ref;
