@@ -163,6 +163,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     L, states = aut.max_pattern_len, aut.num_states
     matcher = Matcher(aut, ctx["local_rank"], max_text=16, plane_capacity=2)
     matcher.set_mode(args.mode)
+    if args.chain_bytes:
+        matcher.set_chain_bytes(args.chain_bytes)
     aut.close()
     log(rank, "%s: %d states, L=%d, compile %.2fs, device %.1f MB, sparse eligible: %s" % (
         wl.name, states, L, t_compile, matcher.device_bytes / 1e6, matcher.sparse_eligible()))
@@ -213,6 +215,14 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     gather_stream = torch.cuda.Stream(device=dev)
     pe = max(1, args.profile_every)
 
+    Geff = G if args.issue != "main" else 1
+
+    def timed(i):
+        """is worker 0's i-th step of a block one whose kernels are timed?  Whole launch groups only,
+        every pe-th of them, and only groups that are full."""
+        grp = i // Geff
+        return grp % pe == 0 and (grp + 1) * Geff <= len(range(0, K, W))
+
     def batches(profile):
         out = []
         for k in range(K):
@@ -220,7 +230,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             out.append(matcher.make_batch(d_texts[k % ntexts], n_local, streams[w].cuda_stream, p[0], p[1], cap,
                                           (wss[w][(k // W) % G], ws_bytes), halo=plan["halo"],
                                           offset_shift=plan["offset_shift"],
-                                          profile=profile and w == 0 and (k // W) % pe == 0))
+                                          profile=profile and w == 0 and timed(k // W)))
         return out
 
     plain, profiled = batches(False), batches(True)
@@ -305,6 +315,18 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                                            offset_shift=plan["offset_shift"], profile=True))
         torch.cuda.synchronize()
     s_k1, s_k2, s_pipe, s_n = matcher.profile_read()
+    # ... and one launch group of Geff batches in flight, alone
+    g_k1 = g_k2 = g_pipe = 0.0
+    g_n = 0
+    if Geff > 1:
+        gsc = torch.zeros((Geff, 2, cap), dtype=torch.int32, device=dev)
+        for i in range(6):
+            matcher.enqueue_many([matcher.make_batch(d_texts[(i * Geff + j) % ntexts], n_local, streams[0].cuda_stream,
+                                                     gsc[j][0], gsc[j][1], cap, (wss[0][j], ws_bytes), halo=plan["halo"],
+                                                     offset_shift=plan["offset_shift"], profile=True)
+                                  for j in range(Geff)])
+            torch.cuda.synchronize()
+        g_k1, g_k2, g_pipe, g_n = matcher.profile_read()
     path = matcher.path_taken(n_local, streams[0].cuda_stream, workspace=(wss[0][0].data_ptr(), ws_bytes))
 
     red = dev if ctx["backend"] == "nccl" else torch.device("cpu")
@@ -384,7 +406,9 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         # k_spec_walk of the chain pipeline): algorithmic bytes = N x 1 B of text + 8 B per record
         #  over that kernel's average duration, HIP events on the worker's own stream
         # inside the timed region.
-        alg_bytes = n_local + 8 * m_local
+        alg_batch = n_local + 8 * m_local
+        grouped = Geff if path == "sparse" else 1            # batches one launch of the bulk kernel processes
+        alg_bytes = alg_batch * grouped
         kname = "k_sieve" if path == "sparse" else "k_spec_walk"
         L1 = max(launches, 1)
         k_s = k1_ms / 1e3 / L1
@@ -396,6 +420,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             for name, rec in json.load(open(tfile)).items():
                 stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
             traffic = stage_traffic.get(kname)
+            if traffic is not None:
+                traffic = round(traffic * grouped, 1)     # (the counters were collected with one batch per launch)
         out = {
             "value": round(value, 3),
             "ms_per_step": round(elapsed / K * 1e3, 5),
@@ -430,14 +456,15 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "batches_per_launch": grouped,
                 "kernel_us": round(k_s * 1e6, 2),
                 "rest_of_pipeline_us": round(k2_ms / L1 * 1e3, 2),
                 "pipeline_us": round(pipe_ms / L1 * 1e3, 2),
                 "launches_timed": launches,
                 "stage_traffic": stage_traffic or None,
-                "note": "HIP events on the worker's own stream around the kernels of every %d-th step of worker 0 in "
-                        "the last timed block; with %d batches in flight a kernel shares the GPU with the other "
-                        "batches' kernels" % (pe, W),
+                "note": "HIP events on the worker's own stream around the kernels of every %d-th launch group of worker 0 "
+                        "in the last timed block; with %d workers a kernel shares the GPU with the other workers' "
+                        "kernels" % (pe, W),
             },
         }
         if s_n:
@@ -446,9 +473,20 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "kernel_us": round(sk * 1e6, 2),
                 "rest_of_pipeline_us": round(s_k2 / s_n * 1e3, 2),
                 "pipeline_us": round(s_pipe / s_n * 1e3, 2),
-                "achieved": round(alg_bytes / sk / 1e9, 2),
-                "frac": round(alg_bytes / sk / 1e9 / HBM_PEAK_GBS, 5),
+                "achieved": round(alg_batch / sk / 1e9, 2),
+                "frac": round(alg_batch / sk / 1e9 / HBM_PEAK_GBS, 5),
                 "launches": s_n,
+            }
+        if g_n and path == "sparse":
+            gk = g_k1 / 1e3 / g_n
+            out["roofline_one_group_in_flight"] = {
+                "batches_per_launch": Geff,
+                "kernel_us": round(gk * 1e6, 2),
+                "rest_of_pipeline_us": round(g_k2 / g_n * 1e3, 2),
+                "pipeline_us": round(g_pipe / g_n * 1e3, 2),
+                "achieved": round(alg_batch * Geff / gk / 1e9, 2),
+                "frac": round(alg_batch * Geff / gk / 1e9 / HBM_PEAK_GBS, 5),
+                "launches": g_n,
             }
         if e2e is not None:
             out["e2e_with_h2d"] = e2e
@@ -472,6 +510,7 @@ def main():
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=4, help="batches in flight: HIP streams, one host thread each")
+    ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
     ap.add_argument("--group", type=int, default=4,
                     help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..4")
     ap.add_argument("--issue", default="threads", choices=["threads", "native", "main"],

@@ -923,12 +923,12 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 // that wait for nothing and are not timed: one group for the sparse kernels
 bool groupable(const acm_dfa *d, const acm_scan_batch &b)
 {
-	return !d->profile && !b.profile && !b.wait_before_walk && !b.record_after_walk && b.n > 0;
+	return !d->profile && !b.wait_before_walk && !b.record_after_walk && b.n > 0;
 }
 bool joins(const acm_scan_batch *const *group, uint32_t m, const acm_scan_batch &b)
 {
-	if (b.stream != group[0]->stream || b.n != group[0]->n)
-		return false;
+	if (b.stream != group[0]->stream || b.n != group[0]->n || (b.profile != 0) != (group[0]->profile != 0))
+		return false;   // (a group is timed as a whole or not at all)
 	for (uint32_t i = 0; i < m; i++)
 		if (b.d_workspace == group[i]->d_workspace || b.d_pat_plane == group[i]->d_pat_plane ||
 		    b.d_off_plane == group[i]->d_off_plane)
@@ -960,8 +960,29 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 			acm::SieveJob jobs[8];
 			for (uint32_t i = 0; i < m && rc == ACM_OK; i++)
 				rc = enqueue_batch(d, group[i], true, &jobs[i]);
+			hipStream_t gs = (hipStream_t)group[0]->stream;
+			hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+			if (rc == ACM_OK && group[0]->profile) {   // the group's kernels, timed like a single batch's
+				std::lock_guard<std::mutex> lock(d->profile_mutex);
+				for (auto &e : ev) {
+					if (!d->profile_pool.empty()) {
+						e = (hipEvent_t)d->profile_pool.back();
+						d->profile_pool.pop_back();
+					} else if (hipEventCreate(&e) != hipSuccess) {
+						return acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventCreate failed");
+					}
+				}
+			}
+			if (rc == ACM_OK && ev[0])
+				ACM_HIP_TRY(hipEventRecord(ev[0], gs));
 			if (rc == ACM_OK)
-				rc = acm::sparse_group_enqueue(d, jobs, m, (hipStream_t)group[0]->stream, nullptr, nullptr);
+				rc = acm::sparse_group_enqueue(d, jobs, m, gs, ev[1], ev[2]);
+			if (rc == ACM_OK && ev[0]) {
+				ACM_HIP_TRY(hipEventRecord(ev[3], gs));
+				std::lock_guard<std::mutex> lock(d->profile_mutex);
+				for (auto e : ev)
+					d->profile_events.push_back((void *)e);
+			}
 		}
 		m = 0;
 		return rc;
@@ -1182,6 +1203,15 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 		S = 16;
 		while (S < 256 && (size_t)S * 2 * lanes <= n)
 			S *= 2;
+		// halo mode walks L - 1 bytes per chain twice: with half the waves of every CU still busy a
+		// chain of four halos is the better deal when batches are in flight side by side (sentiment
+		// set, 32 MiB: 650 instead of 574 GB/s; alone the walk takes 89 instead of 56 us)
+		const uint32_t hb = ((d->max_pattern_len > 1 ? d->max_pattern_len - 1 : 0u) + 15u) & ~15u;
+		uint32_t want = 16;
+		while (want < 4 * hb)
+			want *= 2;
+		if (d->use_halo && C == 4 && hb > 0 && hb <= S && want > S && want <= 256 && (size_t)want * lanes <= 2 * n)
+			S = want;
 	}
 	uint32_t logS = 0;
 	while ((1u << logS) < S)
@@ -1248,7 +1278,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 	}
 
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-	const bool profile = d->profile || batch->profile;
+	const bool profile = !defer && (d->profile || batch->profile);   // (a deferred batch is timed with its group)
 	if (profile) {
 		std::lock_guard<std::mutex> lock(d->profile_mutex);
 		for (auto &e : ev) {
