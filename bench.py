@@ -11,7 +11,10 @@ library's sparse pipeline for signature sets whose shortest pattern has 3 bytes 
 sieve -> exact prefix check -> trie-path followers -> ordered emit; three kernels), its chain
 pipeline otherwise (--mode forces one).  Like the reference, which keeps -w worker threads in
 flight on one device, each with its own queue and buffers (ocl_aho_grep.c:37-144, :498-502),
---workers host threads each drive a HIP stream with private scratch.  The steps rotate over
+the steps of a block are dealt over --workers HIP streams with private scratch and handed to
+the library with one acm_scan_batches_async call (--issue threads: one call per stream, from a
+host thread each); the library puts up to --group consecutive sparse batches of a stream into
+one set of kernel launches (--group 1: a set of launches per step).  The steps rotate over
 --texts distinct 32 MiB texts (more than the 256 MiB Infinity Cache in total), so the text a
 step reads comes from HBM.  The timed region is --repeats blocks of --steps steps, each block
 bracketed by a barrier + device synchronisation; the line reports the median block.
@@ -168,6 +171,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     aut.close()
     log(rank, "%s: %d states, L=%d, compile %.2fs, device %.1f MB, sparse eligible: %s" % (
         wl.name, states, L, t_compile, matcher.device_bytes / 1e6, matcher.sparse_eligible()))
+    if workers <= 0:
+        # automatic: the sparse pipeline's batches go eight to a launch, three streams of such groups keep
+        # the bulk kernel busy; the chain pipeline has a set of launches per batch and wants four
+        workers = 3 if (matcher.sparse_eligible() and args.mode != "chain") else 4
 
     # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
     #      loads its range plus the halo in front of it -------------------------------------------
@@ -204,7 +211,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
     # a worker's consecutive steps alternate between G workspaces: acm_scan_batches_async then puts
     # up to G of them into one set of launches (--group 1: every step has its own three launches)
-    G = max(1, min(args.group, 4))
+    G = max(1, min(args.group, 8))
     G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
     wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
     # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
@@ -218,10 +225,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     Geff = G if args.issue != "main" else 1
 
     def timed(i):
-        """is worker 0's i-th step of a block one whose kernels are timed?  Whole launch groups only,
-        every pe-th of them, and only groups that are full."""
-        grp = i // Geff
-        return grp % pe == 0 and (grp + 1) * Geff <= len(range(0, K, W))
+        """is worker 0's i-th step of a block one whose kernels are timed?  Whole launch groups, every
+        pe-th of them."""
+        return (i // Geff) % pe == 0
+
+    timed_steps = sum(1 for i in range(len(range(0, K, W))) if timed(i))
 
     def batches(profile):
         out = []
@@ -241,7 +249,19 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     Batch = type(plain[0])
     # the steps of a block as arrays for acm_scan_batches_async: all of them in step order (native),
     # or worker w's share (threads)
-    whole = {id(bs): (Batch * K)(*bs) for bs in (plain, profiled)}
+    # (native: a worker's steps G at a time, the workers in turn -- consecutive entries on one stream
+    # are what the library groups)
+    def native_order(count):
+        per = [list(range(w, count, W)) for w in range(W)]
+        out, r = [], 0
+        while any(r * Geff < len(p) for p in per):
+            for p in per:
+                out.extend(p[r * Geff:(r + 1) * Geff])
+            r += 1
+        return out
+
+    whole = {(id(bs), c): (Batch * c)(*[bs[k] for k in native_order(c)])
+             for bs in (plain, profiled) for c in {K, min(K, max(warmup, W))}}
     share = {id(bs): [(Batch * len(bs[w::W]))(*bs[w::W]) for w in range(W)] for bs in (plain, profiled)}
 
     def issue(bs, count):
@@ -255,7 +275,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 check(rc, "acm_scan_batches_async")
         t = time.perf_counter()
         if native:
-            rc = enq_many(dfa, whole[id(bs)], count)
+            rc = enq_many(dfa, whole[(id(bs), count)], count)
             if rc:
                 check(rc, "acm_scan_batches_async")
         elif pool is not None:
@@ -407,8 +427,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         #  over that kernel's average duration, HIP events on the worker's own stream
         # inside the timed region.
         alg_batch = n_local + 8 * m_local
-        grouped = Geff if path == "sparse" else 1            # batches one launch of the bulk kernel processes
-        alg_bytes = alg_batch * grouped
+        # batches one launch of the bulk kernel processes (the timed groups' average: the last group
+        # of a block may be short)
+        grouped = (timed_steps / max(launches, 1)) if (path == "sparse" and launches) else 1
+        alg_bytes = int(alg_batch * grouped)
         kname = "k_sieve" if path == "sparse" else "k_spec_walk"
         L1 = max(launches, 1)
         k_s = k1_ms / 1e3 / L1
@@ -418,12 +440,14 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         tfile = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % wl.name)
         if os.path.exists(tfile):
             for name, rec in json.load(open(tfile)).items():
-                stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
+                if name.startswith("k_"):     # (the short names; the file also has the full ones and the copies)
+                    stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
             traffic = stage_traffic.get(kname)
             if traffic is not None:
                 traffic = round(traffic * grouped, 1)     # (the counters were collected with one batch per launch)
         out = {
             "value": round(value, 3),
+            "steps": K,
             "ms_per_step": round(elapsed / K * 1e3, 5),
             "timed_region_ms": round(elapsed * 1e3, 3),
             "blocks_ms": [round(b * 1e3, 3) for b in blocks],
@@ -456,7 +480,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "batches_per_launch": grouped,
+                "batches_per_launch": round(grouped, 2),
                 "kernel_us": round(k_s * 1e6, 2),
                 "rest_of_pipeline_us": round(k2_ms / L1 * 1e3, 2),
                 "pipeline_us": round(pipe_ms / L1 * 1e3, 2),
@@ -464,7 +488,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "stage_traffic": stage_traffic or None,
                 "note": "HIP events on the worker's own stream around the kernels of every %d-th launch group of worker 0 "
                         "in the last timed block; with %d workers a kernel shares the GPU with the other workers' "
-                        "kernels" % (pe, W),
+                        "kernels.  traffic = the bulk kernel's counted HBM bytes for ONE batch (profiles/, collected "
+                        "with --group 1) x batches_per_launch; stage_traffic: per batch" % (pe, W),
             },
         }
         if s_n:
@@ -509,13 +534,14 @@ def main():
                     help="workloads reported as sub-records of the line (N = 1 only); '' for none")
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
-    ap.add_argument("--workers", type=int, default=4, help="batches in flight: HIP streams, one host thread each")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="HIP streams the steps are dealt over (0: automatic, 3 for the sparse pipeline, 4 for chain)")
     ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
-    ap.add_argument("--group", type=int, default=4,
-                    help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..4")
-    ap.add_argument("--issue", default="threads", choices=["threads", "native", "main"],
-                    help="who enqueues the steps: one host thread per worker, one acm_scan_batches_async call, "
-                         "or the main thread step by step")
+    ap.add_argument("--group", type=int, default=8,
+                    help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..8")
+    ap.add_argument("--issue", default="native", choices=["native", "threads", "main"],
+                    help="who enqueues the steps of a block: one acm_scan_batches_async call from the main thread, one "
+                         "host thread per worker (each with one such call), or the main thread step by step")
     ap.add_argument("--mode", default="auto", choices=["auto", "chain", "sparse"],
                     help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -580,7 +606,7 @@ def main():
             "value": head["value"],
             "unit": "GB/s",
             "n_gpus": world,
-            "steps": max(args.workers, args.steps),
+            "steps": head["steps"],
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,

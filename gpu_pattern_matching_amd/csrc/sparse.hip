@@ -136,12 +136,12 @@ struct SieveArgs {
 	uint32_t plane_capacity;
 };
 
-// A launch takes up to kMaxGroup batches of the same size (acm_scan_batches_async): the bulk
+// A launch takes up to kMaxGroup (8) batches of the same size (acm_scan_batches_async): the bulk
 // kernel's waves go through the tiles of one batch after the other, the check and emit kernels
 // get a share of workgroups per batch.  The kernels' fixed costs -- launch, filter fill, the
 // chains of dependent loads of the check kernel -- are paid once per group instead of once
 // per batch.
-constexpr uint32_t kMaxGroup = 4;
+constexpr uint32_t kMaxGroup = 8;
 // What travels in the argument buffer: the tables and the geometry once (a group's batches have
 // one size), 64 bytes per batch; a kernel puts the SieveArgs of its batch together from both (the
 // fields it does not use cost nothing).  An argument buffer of 4 x SieveArgs -- 1.2 KB -- made
@@ -808,10 +808,7 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 		return v & 0xFFFFFFu;
 	};
 	const uint32_t tile_first = blockIdx.x * kWaves + wv;
-	// every batch's scalars now, with the filter still on its way (fetched where a batch starts they
-	// would be a scalar-memory round trip in front of its first loads)
-	const BulkBatch b0(batch_view(g, 0)), b1(batch_view(g, 1)), b2(batch_view(g, 2)), b3(batch_view(g, 3));
-	static_assert(kMaxGroup == 4, "the bulk kernel's batch loop is unrolled four times");
+	const BulkBatch b0(batch_view(g, 0));   // the first batch's scalars now, with the filter still on its way
 	unsigned long long *stamp = DBG && g.common.stamps ? g.common.stamps + (size_t)tile_first * 8 : nullptr;
 	if (DBG && stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -845,11 +842,8 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	const unsigned long long lt = (1ull << lane) - 1ull;   // the lanes in front of this one
 
 	bool first = true;
-#pragma unroll
-	for (uint32_t bi = 0; bi < kMaxGroup; bi++) {
-		if (bi >= g.count)
-			break;
-		const BulkBatch &a = bi == 0 ? b0 : bi == 1 ? b1 : bi == 2 ? b2 : b3;
+	for (uint32_t bi = 0; bi < g.count; bi++) {
+		const BulkBatch a(batch_view(g, bi));   // (a scalar-cache hit per batch: the workgroup's waves read the same lines)
 		uint32_t tile = tile_first, off = 0;
 		uint32_t qn = 0;   // samples of the current tile written so far
 		while (tile < a.ntiles) {
@@ -1344,8 +1338,8 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	grp.count = count;
 	Geometry g;
 	fill_common(d, n, grp, g);
-	for (uint32_t i = 0; i < kMaxGroup; i++)   // (the bulk kernel reads all four: the spare ones repeat the last)
-		fill_batch(jobs[i < count ? i : count - 1], grp.b[i]);
+	for (uint32_t i = 0; i < count; i++)
+		fill_batch(jobs[i], grp.b[i]);
 	SieveArgs &a = grp.common;
 	static unsigned long long *d_stamps = nullptr;
 	const bool want_stamps = count == 1 && getenv("ACM_SIEVE_STAMPS") != nullptr;

@@ -224,15 +224,15 @@ int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
  * enqueued).
  *
  * Grouping: consecutive batches that take the sparse pipeline, have the same
- * stream and size, each its OWN workspace and planes, no events and no
- * profiling, are enqueued up to acm_scan_set_max_group() at a time as ONE set
+ * stream and size, each its OWN workspace and planes and no events, are
+ * enqueued up to acm_scan_set_max_group() at a time as ONE set
  * of three launches -- the kernels' fixed costs (launch, filter fill, the
  * check kernel's chains of dependent loads) are paid per group instead of per
  * batch.  Results are those of enqueueing the batches one by one; they become
  * visible in stream order when the group's last kernel has run.  Batches that
  * share a workspace are never grouped. */
 int acm_scan_batches_async(const acm_dfa *, const acm_scan_batch *batches, size_t count);
-/* batches per group, 1 (never group) .. 4 (default).  Returns the value in use;
+/* batches per group, 1 (never group) .. 8 (the default).  Returns the value in use;
  * 0 or negative only queries. */
 int acm_scan_set_max_group(acm_dfa *, int batches);
 
