@@ -42,7 +42,7 @@
 // state after the last D-1 bytes from the root (depth < D there).
 //
 // Three launches, no host round trip between them:
-//   k_sieve        the bulk pass.  One workgroup of 8 waves per CU with the Bloom filter
+//   k_sieve        the bulk pass.  Workgroups of 8 waves (one per CU and launch) with the Bloom filter
 //                  in LDS; a wave owns a tile of the text at a time: reads it 16 B per
 //                  lane, probes one 3-gram per W bytes, appends {position, 3-gram} of what
 //                  the filter flags to the tile's sample list (ranks from ballots).
@@ -1351,14 +1351,16 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		a.stamps = d_stamps;
 	}
 
-	// K1: persistent workgroups of 8 waves, a tile per wave at a time, ONE workgroup per CU (it asks
-	// for more than half of the LDS whatever the filter's size): 8 waves with 8 KiB in flight each
-	// keep the memory system as busy as 16 do (measured: 16 are 1 us slower per launch, 4 are 3 us
-	// slower; a second register set prefetching the wave's next tile gains nothing either), and
-	// three quarters of the CU's wave slots and registers stay free for the check and emit kernels
-	// of the batches in flight on other streams -- with two bulk kernels resident everywhere those
-	// would wait for a whole bulk workgroup to drain, every time.
-	const size_t lds = std::max((size_t)a.bloom_words * 4, (size_t)84 * 1024);
+	// K1: persistent workgroups of 8 waves, a tile per wave at a time, at most TWO workgroups per CU
+	// (it asks for more than a third of the LDS whatever the filter's size): 8 waves with 8 KiB in
+	// flight each keep the memory system as busy as 16 do (measured: 16 are 1 us slower per launch,
+	// 4 are 3 us slower; a second register set prefetching the wave's next tile gains nothing
+	// either).  One launch fills a CU's first slot; the second slot lets the next stream's bulk
+	// kernel ramp up while this one drains (4.0 instead of 3.8 TB/s), and half of the CU's wave
+	// slots and registers still stay free for the check and emit kernels of the batches in flight
+	// on other streams -- with bulk workgroups resident everywhere those would wait for a whole
+	// bulk workgroup to drain, every time.
+	const size_t lds = std::max((size_t)a.bloom_words * 4, (size_t)56 * 1024);
 	uint32_t blocks = (g.ntiles + kWaves - 1) / kWaves;
 	if (blocks > (uint32_t)d->num_cus)
 		blocks = (uint32_t)d->num_cus;
