@@ -67,8 +67,8 @@ class Workload:
             self.pattern_file = None
             self.what = ("32 MiB per GPU of seeded uniform bytes + %d planted signatures x first %d ClamAV sigs"
                          % (plant, self.sigs))
-            self.cap = 1 << 13
-            while self.cap < 2 * plant + 1024:
+            self.cap = 1 << 13      # records never exceed the planted signatures (uniform bytes match nothing)
+            while self.cap < plant + 1024:
                 self.cap *= 2
         elif name == "sentiment":
             self.sigs = None
@@ -251,8 +251,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     # or worker w's share (threads)
     # (native: a worker's steps G at a time, the workers in turn -- consecutive entries on one stream
     # are what the library groups)
-    def native_order(count):
-        per = [list(range(w, count, W)) for w in range(W)]
+    def native_order(count, lo=0):
+        per = [[k for k in range(lo, count) if k % W == w] for w in range(W)]
         out, r = [], 0
         while any(r * Geff < len(p) for p in per):
             for p in per:
@@ -260,8 +260,25 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             r += 1
         return out
 
+    # N > 1: a block's planes go to rank 0 in up to three gathers, each behind the scans it carries and
+    # beside the scans of the next piece (a piece = whole rounds of launch groups: a contiguous range of
+    # steps, i.e. of plane slots)
+    def pieces(count, n=3):
+        per_round = max(1, Geff * W)
+        rounds = (count + per_round - 1) // per_round
+        out, lo = [], 0
+        for i in range(n):
+            hi = min(count, ((rounds * (i + 1) + n - 1) // n) * per_round)
+            if hi > lo:
+                out.append((lo, hi))
+                lo = hi
+        return out
+
     whole = {(id(bs), c): (Batch * c)(*[bs[k] for k in native_order(c)])
              for bs in (plain, profiled) for c in {K, min(K, max(warmup, W))}}
+    chunked = native and dist.is_initialized() and slots == K
+    piecewise = {id(bs): [(lo, hi, (Batch * (hi - lo))(*[bs[k] for k in native_order(hi, lo)])) for lo, hi in pieces(K)]
+                 for bs in (plain, profiled)} if chunked else {}
     share = {id(bs): [(Batch * len(bs[w::W]))(*bs[w::W]) for w in range(W)] for bs in (plain, profiled)}
 
     def issue(bs, count):
@@ -293,22 +310,41 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather():
+    def gather(lo=0, hi=None):
         if not dist.is_initialized():
             return
-        for s in streams:                               # behind every worker's scans
+        hi = planes.shape[0] if hi is None else hi
+        mine = planes[lo:hi]
+        for s in streams:                               # behind every worker's scans so far
             gather_stream.wait_stream(s)
         with torch.cuda.stream(gather_stream):
             if ctx["backend"] == "nccl":
-                dist.gather(planes, gather_list=(gathered or [torch.empty_like(planes)]) if rank == 0 else None, dst=0)
+                into = [g[lo:hi] for g in gathered] if gathered is not None else [torch.empty_like(mine)]
+                dist.gather(mine, gather_list=into if rank == 0 else None, dst=0)
             else:                                       # rehearsal on one GPU: through the host
                 gather_stream.synchronize()
-                host = planes.cpu()
+                host = mine.cpu()
                 bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, gather_list=bufs, dst=0)
                 if rank == 0 and gathered is not None:
                     for g, h in zip(gathered, bufs):
-                        g.copy_(h)
+                        g[lo:hi].copy_(h)
+
+    def block(bs):
+        """the K steps of a block and the gather of their planes; returns the host's enqueue seconds"""
+        if not chunked:
+            t = issue(bs, K)
+            gather()
+            return t
+        t = 0.0
+        for lo, hi, arr in piecewise[id(bs)]:
+            t0 = time.perf_counter()
+            rc = enq_many(dfa, arr, hi - lo)
+            if rc:
+                check(rc, "acm_scan_batches_async")
+            t += time.perf_counter() - t0
+            gather(lo, hi)
+        return t
 
     issue(plain, min(K, max(warmup, W)))
     gather()
@@ -318,8 +354,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     for rep in range(max(1, repeats)):
         fence()
         t0 = time.perf_counter()
-        host_issue.append(issue(profiled if rep == repeats - 1 else plain, K))
-        gather()
+        host_issue.append(block(profiled if rep == repeats - 1 else plain))
         fence()
         blocks.append(time.perf_counter() - t0)
     k1_ms, k2_ms, pipe_ms, launches = matcher.profile_read()
