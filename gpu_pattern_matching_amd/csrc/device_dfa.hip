@@ -105,6 +105,22 @@ int build_sieve(const acm_automaton &a, acm_dfa *d)
 	const uint32_t D = (uint32_t)std::min<size_t>(shortest, acm::kSieveMaxPrefix);
 	d->sv_stride = W;
 	d->sv_prefix_len = D;
+	// runs of one byte that can start a pattern: D copies of b down the trie
+	memset(d->sv_run_ok, 0, sizeof(d->sv_run_ok));
+	for (uint32_t b = 0; b < 256; b++) {
+		uint32_t s = 0, k = 0;
+		for (; k < D; k++) {
+			uint32_t next = UINT32_MAX;
+			for (uint32_t e = a.child_begin[s]; e < a.child_begin[s + 1]; e++)
+				if (a.child_list[e].byte == b)
+					next = a.child_list[e].to;
+			if (next == UINT32_MAX)
+				break;
+			s = next;
+		}
+		if (k == D)
+			d->sv_run_ok[b >> 5] |= 1u << (b & 31);
+	}
 
 	// 3-grams at offsets < W of every pattern, with the offsets they occur at
 	std::unordered_map<uint32_t, uint32_t> grams;

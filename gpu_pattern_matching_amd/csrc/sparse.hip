@@ -91,6 +91,7 @@ constexpr uint32_t kSummaryWords = 8;      // per tile: extent + 1, hits, first,
 constexpr uint32_t kGaveUp = 0xFFFFFFFFu;  // hit count of a tile whose list was full (cannot happen: geometry_for)
 constexpr uint32_t kMarkerFailed = 0xDEADu; // path marker of a scan that did not produce planes
 constexpr uint32_t kDenseDivisor = 128;    // more than a record per this many bytes: a dense batch
+constexpr uint32_t kBusyDivisor = 256;     // ... or a flagged sample per this many: the check kernel's time, not the bulk kernel's, is the batch's
 constexpr int kEmitBlock = 1024;
 constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // checker waves + the carried-state walker
 constexpr uint32_t kRowsPerThread = (kMaxRows + kEmitBlock - 1) / kEmitBlock;
@@ -113,6 +114,7 @@ struct SieveArgs {
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	uint32_t F, D;
+	uint32_t run_ok[8];           // bit b: D copies of byte b are a trie path (a run of b can start a pattern)
 	// text
 	const uint4 *text16;
 	const uint8_t *text;
@@ -128,7 +130,7 @@ struct SieveArgs {
 	uint32_t scap;
 	uint32_t *summary;   // [nrows][kSummaryWords]; row 0: the carried-state walker, row 1 + w: checker wave w
 	uint2 *lists;        // [nrows][cap] {position, plane value}, ascending
-	uint32_t *misc;      // [0] state after the last D-1 bytes from the root
+	uint32_t *misc;      // [0] state after the last D-1 bytes from the root, [1] flagged samples of the batch
 	uint32_t *path_marker, *giveups;
 	unsigned long long *stamps;   // debugging aid (ACM_SIEVE_STAMPS): [wave][8] clock readings, or null
 	// output
@@ -812,6 +814,8 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	unsigned long long *stamp = DBG && g.common.stamps ? g.common.stamps + (size_t)tile_first * 8 : nullptr;
 	if (DBG && stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
+	if (blockIdx.x == 0 && threadIdx.x < g.count)   // the batches' sample counters (the check kernel adds to them)
+		((uint32_t *)(g.b[threadIdx.x].ws + g.o_misc))[1] = 0;
 	{
 		// The filter goes to LDS by DMA (no registers, nothing waits yet), 1 KiB pieces dealt over the
 		// waves; then the text loads; then a wait for the filter only -- the text keeps arriving
@@ -895,7 +899,30 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 			if (__ballot(f != 0)) {
 #pragma unroll
 				for (uint32_t j = 0; j < LOADS; j++) {
-					const uint32_t fj = (f >> (j * S)) & SMASK;
+					uint32_t fj = (f >> (j * S)) & SMASK;
+					if (!__ballot(fj != 0))
+						continue;
+					{
+						// Runs (zero pages, padding): a lane whose 16 bytes are one byte b, between two lanes
+						// that hold the same, sees nothing but b in every window a candidate of its samples
+						// could start in ([p - W + 1, p + D), D <= 10) -- unless D copies of b are a trie path,
+						// none of them is a pattern's prefix, and the check kernel is spared a tile full of
+						// samples.
+						const uint32_t x = w[j].x;
+						const bool same = w[j].y == x && w[j].z == x && w[j].w == x && __builtin_amdgcn_alignbyte(x, x, 1) == x;
+						const unsigned long long sm = __ballot(same);
+						if (__ballot(same && fj != 0)) {
+							const uint32_t xl = __shfl_up(x, 1, 64), xr = __shfl_down(x, 1, 64);
+							const uint32_t b = x & 0xFFu, wi = b >> 5;
+							uint32_t word = g.common.run_ok[0];
+#pragma unroll
+							for (uint32_t i = 1; i < 8; i++)
+								word = wi == i ? g.common.run_ok[i] : word;
+							const bool inner = lane > 0 && lane < 63 && ((sm >> (lane - 1)) & 5ull) == 5ull && xl == x && xr == x;
+							if (same && inner && !((word >> (b & 31u)) & 1u))
+								fj = 0;
+						}
+					}
 					if (!__ballot(fj != 0))
 						continue;
 					const uint32_t pos0 = base + j * 1024 + lane * 16;
@@ -980,6 +1007,8 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 	for (uint32_t k = 0; k < kTilesPerChecker; k++)
 		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)(k * kSpecLanes));
 	const uint32_t nsamples = cum[kTilesPerChecker];
+	if (lane == 0 && nsamples)
+		__hip_atomic_fetch_add(a.misc + 1, nsamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for AUTO mode (emit)
 	uint32_t r0 = 0;
 	if (nsamples && !__ballot(mycount > kSpecLanes)) {
 		dbg_rounds++;
@@ -1198,8 +1227,10 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		a.pat_plane[tail] = last_ref;
 		a.off_plane[tail] = last_ref;
 		*a.path_marker = (uint32_t)ACM_SCAN_MODE_SPARSE;
-		// a batch this dense in matches is the chain pipeline's: AUTO mode counts them (scan.hip, pick_sparse)
-		if (a.giveups && all_cells > a.n / kDenseDivisor)
+		// a batch this dense in matches, or with this many samples for the check kernel to look at (real
+		// binaries: common 3-grams of code), is the chain pipeline's: AUTO mode counts them (scan.hip,
+		// pick_sparse)
+		if (a.giveups && (all_cells > a.n / kDenseDivisor || a.misc[1] > a.n / kBusyDivisor))
 			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	if (stamp)
@@ -1285,6 +1316,7 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.dev2ref = d->d_dev2ref;
 	a.F = d->first_final;
 	a.D = d->sv_prefix_len;
+	memcpy(a.run_ok, d->sv_run_ok, sizeof(a.run_ok));
 	a.n = (uint32_t)n;
 	a.n_pad = (uint32_t)((n + 15) & ~(size_t)15);
 	a.tile_bytes = g.tile_bytes;

@@ -363,6 +363,29 @@ def test_auto_mode_hands_dense_batches_to_the_chain_pipeline(gpu):
     m.close()
 
 
+def test_auto_mode_counts_sample_heavy_batches(gpu):
+    """AUTO also leaves the sparse pipeline for texts without a single match whose sampled 3-grams
+    keep hitting the pattern set (real binaries: common 3-grams of code and tables): more than a
+    flagged sample per 256 bytes is the check kernel's time, not the bulk kernel's."""
+    pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 400)
+    a, o = build(pats)
+    n = 1 << 20
+    rng = np.random.default_rng(5)
+    text = rng.integers(0, 256, size=n, dtype=np.uint8)
+    for p in range(8, n - 8, 8):                  # at every sampled position the 3-gram at offset 2 of some signature
+        g = np.frombuffer(pats[(p >> 3) % len(pats)][2:5], dtype=np.uint8)
+        text[p:p + 3] = g
+    exp = o.scan(text)
+    m = Matcher(a, 0, max_text=n)
+    m.set_mode("auto")
+    paths = []
+    for i in range(16 + 4):
+        assert_same(m.scan(text), exp)
+        paths.append(m.path_taken(n))
+    assert paths[:16] == ["sparse"] * 16 and paths[16:] == ["chain"] * 4
+    m.close()
+
+
 def test_real_binary_content(gpu):
     """Not synthetic: 48 MiB out of the middle of the largest ROCm library on the box (code, zero
     pages, tables, strings) x 2000 and 15000 signatures.  Whatever path the data makes the sparse
