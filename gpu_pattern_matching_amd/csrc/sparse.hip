@@ -51,15 +51,18 @@
 //                  prefix lookups for 64 samples at a time (stage 1), then 64 followers
 //                  at a time (stage 2), shadow inside the wave, hits appended to the
 //                  wave's row in position order, a 32-byte row summary.  Latency-bound,
-//                  a thousand waves of dependent loads; it runs beside the next batch's
+//                  five hundred waves of dependent loads; it runs beside the next batch's
 //                  bulk pass.  Its last workgroup walks the carried state instead.
 //   k_sieve_emit   exclusive prefix max / prefix sum over the row summaries, drops the
 //                  shadowed head of each row, copies the records to the planes.
 // Nothing is capped and nothing falls back: a tile's sample list has room for every
 // sample of the tile and a row's hit list for one hit per position its followers can
 // reach (geometry_for); the lists are address space, only what is written is touched.
-// A text that is dense in matches is merely slow here -- the emit kernel counts such
-// batches and AUTO mode moves to the chain pipeline of scan.hip (pick_sparse).
+// A text that is dense in matches, or in 3-grams of the pattern set that are no pattern
+// prefixes (real binaries), is merely slow here -- the emit kernel counts such batches and
+// AUTO mode moves to the chain pipeline of scan.hip (pick_sparse).
+// A launch may carry up to eight batches of one size (SieveGroup, acm_scan_batches_async):
+// the kernels' fixed costs are then paid once for all of them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
