@@ -103,6 +103,11 @@ class Automaton:
     def max_pattern_len(self):
         return self.lib.acm_automaton_max_pattern_len(self.h)
 
+    def byte_classes(self):
+        """(number of byte classes, byte -> class map as a 256-entry uint8 array); 256 classes: no compression"""
+        m = np.zeros(256, dtype=np.uint8)
+        return int(self.lib.acm_automaton_byte_classes(self.h, m.ctypes.data_as(C.c_void_p))), m
+
     def reference_table(self):
         """The reference-format table [states, 2, 256] int32 (acsmx.c:640-658)."""
         t = np.zeros((self.num_states, 2, 256), dtype=np.int32)

@@ -511,6 +511,15 @@ extern "C" int acm_automaton_max_pattern_len(const acm_automaton *a)
 	return a ? a->max_pattern_len : 0;
 }
 
+extern "C" int acm_automaton_byte_classes(const acm_automaton *a, uint8_t *class_of)
+{
+	if (!a || !a->compiled)
+		return 0;
+	if (class_of)
+		memcpy(class_of, a->byte_class, 256);
+	return (int)a->num_classes;
+}
+
 extern "C" int acm_automaton_num_states(const acm_automaton *a)
 {
 	return (a && a->compiled) ? (int)a->num_states : 0;

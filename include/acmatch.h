@@ -81,6 +81,11 @@ int acm_automaton_compile(acm_automaton *);
 
 int acm_automaton_num_patterns(const acm_automaton *);
 int acm_automaton_max_pattern_len(const acm_automaton *);
+/* byte classes of a compiled automaton: bytes that occur in no pattern share
+ * one DFA column, every other byte has its own.  256 = every byte its own
+ * (no compression).  class_of, if not NULL, gets the 256-entry byte -> class
+ * map.  The chain pipeline's planes have one cell per class. */
+int acm_automaton_byte_classes(const acm_automaton *, uint8_t *class_of);
 /* states as acsm_get_states reports them after acsm_gen_state_table */
 int acm_automaton_num_states(const acm_automaton *);
 /* bytes of the reference's serialised table: states * 2 * 256 * 4 */

@@ -117,6 +117,33 @@ def test_add_after_compile_is_refused(lib):
         a.add(b"x", 2)
 
 
+def test_byte_classes(lib):
+    """Bytes no pattern uses share class 0, every used byte has a class of its own; a set that uses
+    (nearly) every byte value is left alone."""
+    a = Automaton()
+    for i, w in enumerate([b"died", b"death", b"lost", b"zebra"]):
+        a.add(w, i + 1)
+    a.compile()
+    n, m = a.byte_classes()
+    used = sorted(set(b"dieddeathlostzebra"))
+    assert n == len(used) + 1
+    assert all(m[b] == 0 for b in range(256) if b not in used)
+    assert sorted(int(m[b]) for b in used) == list(range(1, len(used) + 1))
+    a.close()
+    a = Automaton()
+    a.add(bytes(range(256)), 1)
+    a.compile()
+    n, m = a.byte_classes()
+    assert n == 256 and list(m) == list(range(256))
+    a.close()
+    a = Automaton()
+    path, hx = orc.pattern_set("sentiment")
+    a.load_file(path, hx, -1)
+    a.compile()
+    assert a.byte_classes()[0] == 27              # a-z and "anything else"
+    a.close()
+
+
 def test_lifo_numbering_and_outputs(lib):
     """the LAST pattern gets states 1..n; duplicates and suffixes decide
     which index a final state reports (head of the match list)."""
