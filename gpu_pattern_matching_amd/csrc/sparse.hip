@@ -133,7 +133,7 @@ struct SieveArgs {
 	uint32_t scap;
 	uint32_t *summary;   // [nrows][kSummaryWords]; row 0: the carried-state walker, row 1 + w: checker wave w
 	uint2 *lists;        // [nrows][cap] {position, plane value}, ascending
-	uint32_t *misc;      // [0] state after the last D-1 bytes from the root, [1] flagged samples of the batch
+	uint32_t *misc;      // [0] state after the last D-1 bytes from the root
 	uint32_t *path_marker, *giveups;
 	unsigned long long *stamps;   // debugging aid (ACM_SIEVE_STAMPS): [wave][8] clock readings, or null
 	// output
@@ -540,13 +540,14 @@ struct Row {
 	uint32_t first, last;
 	uint32_t akey, anode;
 	uint32_t gave_up;
+	uint32_t samples;    // flagged samples the row looked at (for AUTO mode: the emit kernel adds them up)
 };
 
 __device__ __forceinline__ void write_summary(const SieveArgs &a, const Row &t, uint32_t row)
 {
 	uint32_t *s = a.summary + (size_t)row * kSummaryWords;
 	*(uint4 *)s = make_uint4(t.carry, t.gave_up ? kGaveUp : t.count, t.first, t.last);
-	*(uint2 *)(s + 4) = make_uint2(t.akey, t.anode);
+	*(uint4 *)(s + 4) = make_uint4(t.akey, t.anode, t.samples, 0);
 }
 
 // Stage 2, one follower per lane (ascending starts): follow, shadow across the lanes, append the
@@ -667,7 +668,7 @@ __device__ void side_walks(const SieveArgs &a)
 		a.misc[0] = st;
 	}
 	Row t;
-	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.samples = 0;
 	uint32_t state = a.init_state, x = 0;   // x: next byte to consume
 	uint32_t run = 0;                        // known unary, non-final path ahead of 'state'
 	while (state != 0) {
@@ -817,8 +818,6 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	unsigned long long *stamp = DBG && g.common.stamps ? g.common.stamps + (size_t)tile_first * 8 : nullptr;
 	if (DBG && stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
-	if (blockIdx.x == 0 && threadIdx.x < g.count)   // the batches' sample counters (the check kernel adds to them)
-		((uint32_t *)(g.b[threadIdx.x].ws + g.o_misc))[1] = 0;
 	{
 		// The filter goes to LDS by DMA (no registers, nothing waits yet), 1 KiB pieces dealt over the
 		// waves; then the text loads; then a wait for the filter only -- the text keeps arriving
@@ -912,9 +911,9 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 						// none of them is a pattern's prefix, and the check kernel is spared a tile full of
 						// samples.
 						const uint32_t x = w[j].x;
-						const bool same = w[j].y == x && w[j].z == x && w[j].w == x && __builtin_amdgcn_alignbyte(x, x, 1) == x;
-						const unsigned long long sm = __ballot(same);
-						if (__ballot(same && fj != 0)) {
+						if (__ballot(fj != 0 && w[j].y == x)) {   // (one compare decides it on any text without runs)
+							const bool same = w[j].y == x && w[j].z == x && w[j].w == x && __builtin_amdgcn_alignbyte(x, x, 1) == x;
+							const unsigned long long sm = __ballot(same);
 							const uint32_t xl = __shfl_up(x, 1, 64), xr = __shfl_down(x, 1, 64);
 							const uint32_t b = x & 0xFFu, wi = b >> 5;
 							uint32_t word = g.common.run_ok[0];
@@ -987,7 +986,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 	if (stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	Row t;
-	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.samples = 0;
 	const uint32_t row = blk + 1;   // row 0 is the carried-state walker's
 	FollowerQueue fq;
 	fq.start = q2[0];
@@ -1010,8 +1009,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 	for (uint32_t k = 0; k < kTilesPerChecker; k++)
 		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)(k * kSpecLanes));
 	const uint32_t nsamples = cum[kTilesPerChecker];
-	if (lane == 0 && nsamples)
-		__hip_atomic_fetch_add(a.misc + 1, nsamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for AUTO mode (emit)
+	t.samples = nsamples;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
 	uint32_t r0 = 0;
 	if (nsamples && !__ballot(mycount > kSpecLanes)) {
 		dbg_rounds++;
@@ -1121,6 +1119,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	__shared__ uint32_t s_base[kMaxRows + 1];   // first output cell of each row
 	__shared__ uint32_t s_drop[kMaxRows];       // shadowed head of each row's list
 	__shared__ unsigned long long s_alive;
+	__shared__ uint32_t s_samples;              // flagged samples of the batch
 	const uint32_t rows = a.nrows;
 	const uint32_t r0 = threadIdx.x * kRowsPerThread;
 	unsigned long long *stamp = a.stamps && threadIdx.x == 0 ? a.stamps + (size_t)(9000 + blk) * 8 : nullptr;
@@ -1130,8 +1129,11 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	// where it is first used: a fetch from the argument buffer in front of every phase)
 	asm volatile("" :: "s"(a.pat_plane), "s"(a.off_plane), "s"(a.plane_capacity), "s"(a.off_shift), "s"(a.lhead),
 	    "s"(a.lists), "s"(a.cap), "s"(a.misc), "s"(a.dev2ref), "s"(a.path_marker), "s"(a.giveups), "s"(a.n));
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0) {
 		s_alive = ~0ull;
+		s_samples = 0;
+	}
+	uint32_t my_samples = 0;
 	uint32_t E[kRowsPerThread], cnt[kRowsPerThread], first[kRowsPerThread], last[kRowsPerThread];
 	uint32_t tmax = 0;
 	bool gave = false;
@@ -1140,11 +1142,12 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	for (uint32_t i = 0; i < kRowsPerThread; i++) {
 		const uint32_t r = r0 + i, rc = min(r, rows - 1);   // (loads without a branch around them: in flight together)
 		uint4 s = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords);
-		uint2 al = *(const uint2 *)(a.summary + (size_t)rc * kSummaryWords + 4);
+		uint4 al = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords + 4);   // alive key, node, samples
 		if (r >= rows) {
 			s = make_uint4(0, 0, 0, 0);
-			al = make_uint2(0, 0);
+			al = make_uint4(0, 0, 0, 0);
 		}
+		my_samples += al.z;
 		E[i] = s.x;
 		cnt[i] = s.y;
 		first[i] = s.z;
@@ -1163,6 +1166,13 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	}
 	if (alive != ~0ull)
 		atomicMin(&s_alive, alive);
+	if (blk == 0) {   // (a wave at a time: five hundred atomics on one LDS word would take longer than the copy below)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			my_samples += __shfl_xor(my_samples, o, 64);
+		if ((threadIdx.x & 63) == 0 && my_samples)
+			atomicAdd(&s_samples, my_samples);
+	}
 	if (stamp)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
 	uint32_t all_max, all_cells;
@@ -1233,7 +1243,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		// a batch this dense in matches, or with this many samples for the check kernel to look at (real
 		// binaries: common 3-grams of code), is the chain pipeline's: AUTO mode counts them (scan.hip,
 		// pick_sparse)
-		if (a.giveups && (all_cells > a.n / kDenseDivisor || a.misc[1] > a.n / kBusyDivisor))
+		if (a.giveups && (all_cells > a.n / kDenseDivisor || s_samples > a.n / kBusyDivisor))
 			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	if (stamp)
