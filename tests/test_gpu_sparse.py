@@ -372,9 +372,9 @@ def test_auto_mode_counts_sample_heavy_batches(gpu):
     n = 1 << 20
     rng = np.random.default_rng(5)
     text = rng.integers(0, 256, size=n, dtype=np.uint8)
-    for p in range(8, n - 8, 8):                  # at every sampled position the 3-gram at offset 2 of some signature
-        g = np.frombuffer(pats[(p >> 3) % len(pats)][2:5], dtype=np.uint8)
-        text[p:p + 3] = g
+    for p in range(8, n - 8, 8):                  # at every sampled position bytes 1..4 of some signature: its 3-gram
+        g = np.frombuffer(pats[(p >> 3) % len(pats)][1:5], dtype=np.uint8)   # at offset 2 with the byte in front of it
+        text[p - 1:p + 3] = g
     exp = o.scan(text)
     m = Matcher(a, 0, max_text=n)
     m.set_mode("auto")

@@ -1,0 +1,4 @@
+timeout -k 10 600 python3 -m pytest tests/test_gpu_sparse.py tests/test_gpu_scan.py -x -q -p no:cacheprovider > gpurun_out/t_s.log 2>&1 || { tail -30 gpurun_out/t_s.log; exit 1; }
+tail -1 gpurun_out/t_s.log
+PROBE_STAMPS=1 timeout -k 10 500 python3 tools/real_data_probe.py 2000 15000 2>&1 | grep -E "sigs|stage-1"
+bash tools/experiments/exp_ab.sh
