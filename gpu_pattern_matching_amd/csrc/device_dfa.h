@@ -50,6 +50,7 @@ struct acm_dfa {
 	// counted by the device in pinned host memory
 	uint32_t *h_giveups = nullptr, *d_giveups = nullptr;
 	mutable std::atomic<uint32_t> sparse_batches{0}, giveups_seen{0}, chain_hold{0};
+	mutable std::atomic<uint32_t> auto_window{16}, auto_next_hold{64};   // batches per look at the counter; chain batches after a bad look
 
 	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies
 	int scan_mode = ACM_SCAN_MODE_AUTO;

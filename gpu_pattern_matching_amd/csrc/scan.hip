@@ -838,9 +838,11 @@ extern "C" int acm_scan_kernel_count(void) { return 4; }
 namespace {
 // Which pipeline the next batch gets.  Tiny texts are not worth the sieve's tables.  In AUTO
 // mode the choice adapts: the sparse pipeline is exact on any text but slow on one that is dense
-// in matches (more than a record per 128 bytes: its emit kernel counts such batches), so when
+// in matches or in flagged samples (its emit kernel counts such batches, sparse.hip), so when
 // half of the last 16 sparse batches were dense the next 64 go to the chain pipeline, then the
-// sparse one is tried again.
+// sparse one is tried again -- for 4 batches; if half of those are dense again the chain
+// pipeline gets four times as many batches as last time (up to 4096), and so on until a look
+// finds the text quiet.
 bool pick_sparse(const acm_dfa *d, size_t n)
 {
 	if (!d->sparse_ok || d->scan_mode == ACM_SCAN_MODE_CHAIN || n < 64)
@@ -852,11 +854,20 @@ bool pick_sparse(const acm_dfa *d, size_t n)
 		if (d->chain_hold.compare_exchange_weak(hold, hold - 1, std::memory_order_relaxed))
 			return false;
 	const uint32_t count = d->sparse_batches.fetch_add(1, std::memory_order_relaxed) + 1;
-	if (count % 16 == 0) {
+	const uint32_t window = d->auto_window.load(std::memory_order_relaxed);
+	if (count >= window) {
+		d->sparse_batches.store(0, std::memory_order_relaxed);
 		const uint32_t seen = *(volatile uint32_t *)d->h_giveups;   // written by k_sieve_emit, may lag
 		const uint32_t before = d->giveups_seen.exchange(seen, std::memory_order_relaxed);
-		if (seen - before >= 8)
-			d->chain_hold.store(64, std::memory_order_relaxed);
+		if (seen - before >= window / 2) {
+			const uint32_t stay = d->auto_next_hold.load(std::memory_order_relaxed);
+			d->chain_hold.store(stay, std::memory_order_relaxed);
+			d->auto_next_hold.store(std::min<uint32_t>(stay * 4, 4096u), std::memory_order_relaxed);
+			d->auto_window.store(4, std::memory_order_relaxed);
+		} else {
+			d->auto_next_hold.store(64, std::memory_order_relaxed);
+			d->auto_window.store(16, std::memory_order_relaxed);
+		}
 	}
 	return true;
 }

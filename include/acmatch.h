@@ -267,8 +267,10 @@ int acm_scan_set_graphs(acm_dfa *, int enable);
  *           that is dense in matches
  *   AUTO    SPARSE when the pattern set allows it -- adaptively: when half of
  *           the last 16 sparse batches held more than a record per 128 bytes
- *           the next 64 go to the chain pipeline, then the sparse one is
- *           tried again
+ *           or more than a flagged sample per 256 (real binaries) the next 64
+ *           go to the chain pipeline; then the sparse one is tried again, 4
+ *           batches at a time, and every bad look quadruples the chain
+ *           pipeline's share (up to 4096 batches)
  * Returns the mode in use after the call; acm_scan_mode(d, -1) only queries. */
 enum { ACM_SCAN_MODE_AUTO = 0, ACM_SCAN_MODE_CHAIN = 1, ACM_SCAN_MODE_SPARSE = 2 };
 int acm_scan_set_mode(acm_dfa *, int mode);

@@ -336,7 +336,8 @@ def test_gibibyte_buffer(gpu):
 def test_auto_mode_hands_dense_batches_to_the_chain_pipeline(gpu):
     """AUTO: after 16 sparse batches of which at least 8 were dense in matches (here: all; more
     than a record per 128 bytes), the next 64 go to the chain pipeline directly; then the sparse
-    pipeline is tried again.  Results are the oracle's throughout; a forced SPARSE mode stays."""
+    pipeline is tried again, 4 batches at a time, and every bad look quadruples the chain
+    pipeline's share.  Results are the oracle's throughout; a forced SPARSE mode stays."""
     a, o = build(SMALL_SETS["nested"])
     m = Matcher(a, 0, max_text=1 << 17)
     endless = np.frombuffer(b"abc" * 40000, dtype=np.uint8)      # a record every byte or so
@@ -344,12 +345,14 @@ def test_auto_mode_hands_dense_batches_to_the_chain_pipeline(gpu):
     exp_endless, exp_quiet = o.scan(endless), o.scan(quiet)
     m.set_mode("auto")
     paths = []
-    for i in range(16 + 64 + 2):
+    for i in range(16 + 64 + 4 + 256 + 2):
         assert_same(m.scan(endless), exp_endless)
         paths.append(m.path_taken(endless.size))
     assert paths[:16] == ["sparse"] * 16
     assert paths[16:80] == ["chain"] * 64
-    assert paths[80:] == ["sparse"] * 2                           # trying again
+    assert paths[80:84] == ["sparse"] * 4                         # trying again, a short look this time
+    assert paths[84:340] == ["chain"] * 256                       # still dense: four times as long on the chain pipeline
+    assert paths[340:] == ["sparse"] * 2
     m.set_mode("sparse")
     for i in range(20):
         assert_same(m.scan(endless), exp_endless)
