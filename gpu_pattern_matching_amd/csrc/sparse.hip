@@ -719,13 +719,13 @@ __device__ void side_walks(const SieveArgs &a)
 // loads) and falls back to waiting for everything.  vmcnt(N) is safe with stores pending: of the
 // operations that must have completed for N to be reached, at most the stores are not loads.
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load16_nt(v4u &dst, const v4u *p)
+__device__ __forceinline__ void load16(v4u &dst, const v4u *p)
 {
-	asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
 }
-__device__ __forceinline__ void load4_nt(uint32_t &dst, const uint32_t *p)
+__device__ __forceinline__ void load4(uint32_t &dst, const uint32_t *p)
 {
-	asm volatile("global_load_dword %0, %1, off nt" : "=v"(dst) : "v"(p));
+	asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p));
 }
 template <int N>
 __device__ __forceinline__ void wait_loads(v4u &x, uint32_t &y)
@@ -776,8 +776,9 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	constexpr int PER = W <= 2 ? 2 : 1;   // load instructions per group
 	// the groups of the sub-block at 'off' of 'tile'.  Always exactly LOADS * PER load instructions,
 	// whatever exists of the tile (what does not exist is read at the start of the text and masked
-	// out): the waits count them.  Non-temporal: the text is read once, the tables the check kernel
-	// needs stay in L2.
+	// out): the waits count them.  Plain loads, not non-temporal ones: the check kernel comes back
+	// for the text around every flagged sample and finds it in the cache hierarchy (with the nt hint
+	// the bench line is 7 % lower: 3.98 vs 4.29 TB/s).
 	auto issue = [&](const BulkBatch &a, uint32_t tile, uint32_t off) {
 		const uint32_t n16 = a.n_pad >> 4;
 		const uint32_t *text32 = (const uint32_t *)a.text16;
@@ -788,9 +789,9 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 			const uint32_t g16 = ((tile * a.tile_bytes + rel) >> 4) + lane;   // wraps only for tiles that do not exist
 			const bool ok = tile < a.ntiles && rel < a.tile_bytes && g16 < n16;
 			present |= (ok ? 1u : 0u) << j;
-			load16_nt(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
+			load16(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
 			if (W <= 2)
-				load4_nt(nx[j], text32 + (ok && g16 + 1 < n16 ? (size_t)g16 * 4 + 4 : 0));
+				load4(nx[j], text32 + (ok && g16 + 1 < n16 ? (size_t)g16 * 4 + 4 : 0));
 			else
 				nx[j] = 0;
 		}
