@@ -973,10 +973,14 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 {
 	__shared__ uint32_t q2[3][kQ2Cap];
 	const uint32_t lane = threadIdx.x;
-	// the workgroups of a launch are dealt over the group's batches, nrows each
-	const uint32_t per = g.common.nrows, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
+	// The workgroups of a launch are dealt over the group's batches, nrows each rounded up to a
+	// multiple of 8: workgroup ids go round the 8 XCDs, and row r of EVERY batch should land on the
+	// XCD whose bulk-kernel workgroup r read the row's tiles a moment ago -- its L2 still has them.
+	const uint32_t per = (g.common.nrows + 7u) & ~7u, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
+	if (blk >= g.common.nrows)
+		return;
 	const SieveArgs a = batch_view(g, bi);
-	if (blk == per - 1) {
+	if (blk == g.common.nrows - 1) {
 		if (threadIdx.x == 0)
 			side_walks(a);
 		return;
@@ -1412,7 +1416,7 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		blocks = (uint32_t)d->num_cus;
 	// K2: a wave per kTilesPerChecker tiles, and one workgroup for the serial walks
 	const uint32_t cwaves = g.nrows - 1;
-	const uint32_t cblocks = cwaves + 1;
+	const uint32_t cblocks = (cwaves + 1 + 7u) & ~7u;   // (a multiple of 8 per batch: k_sieve_check)
 	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
 	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)
 		eblocks *= 2;
