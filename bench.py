@@ -173,8 +173,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         wl.name, states, L, t_compile, matcher.device_bytes / 1e6, matcher.sparse_eligible()))
     if workers <= 0:
         # automatic: the sparse pipeline's batches go eight to a launch, three streams of such groups keep
-        # the bulk kernel busy; the chain pipeline has a set of launches per batch and wants four
-        workers = 3 if (matcher.sparse_eligible() and args.mode != "chain") else 4
+        # the bulk kernel busy; the chain pipeline's walk kernel fills the device by itself, three are enough
+        workers = 3
 
     # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
     #      loads its range plus the halo in front of it -------------------------------------------
@@ -477,6 +477,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             for name, rec in json.load(open(tfile)).items():
                 if name.startswith("k_"):     # (the short names; the file also has the full ones and the copies)
                     stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
+            if kname == "k_spec_walk" and "k_halo_walk" in stage_traffic and "k_spec_walk" not in stage_traffic:
+                kname = "k_halo_walk"     # (halo mode with the text loaded up front: its own kernel)
             traffic = stage_traffic.get(kname)
             if traffic is not None:
                 traffic = round(traffic * grouped, 1)     # (the counters were collected with one batch per launch)
@@ -570,7 +572,7 @@ def main():
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=0,
-                    help="HIP streams the steps are dealt over (0: automatic, 3 for the sparse pipeline, 4 for chain)")
+                    help="HIP streams the steps are dealt over (0: automatic = 3)")
     ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
     ap.add_argument("--group", type=int, default=8,
                     help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..8")

@@ -364,6 +364,8 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 	}
 	if (const char *h = getenv("ACM_SCAN_HALO"))   // debugging aid: 0 = always speculate and resolve
 		d->use_halo = atoi(h) != 0;
+	if (getenv("ACM_SCAN_NO_PRELOAD"))               // debugging aid: halo mode without the up-front text loads
+		d->use_preload = false;
 	if (const char *g = getenv("ACM_SCAN_GRAPHS"))
 		d->use_graphs = atoi(g) != 0;
 	hipDeviceProp_t prop;

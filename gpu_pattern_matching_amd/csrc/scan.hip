@@ -78,6 +78,7 @@ struct ScanArgs {
 	uint32_t ls;            // log2 of the cells per row
 	uint32_t halo_bytes;    // halo mode (below, walk_tile): bytes every chain walks in front of its own; else 0
 	uint32_t halo_mode;
+	uint32_t halo_pre;      // halo mode: the chains' text is loaded up front (k_halo_walk)
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	const uint8_t *in_byte;
@@ -288,7 +289,13 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 // in front of the chain are not counted; the chain's count is final, the tile's total goes to the
 // scatter kernel directly, k_probe and k_resolve are not launched.  A chain less than hb bytes
 // into the text starts at byte 0 in the carried-in state.
-template <int C, bool GUARD, bool CLS, bool HALO>
+// PRE (halo mode, chains of up to five 16-byte groups): all text of the lane's chains is loaded up
+// front, a chain's five loads back to back.  Taken one group per trip through the loop, a 64-byte
+// line of the text is touched by four or five loads many microseconds apart -- lane-per-chain is a
+// gather, 16 bytes per lane at a stride of one chain -- and with 8 MB of such lines in flight per
+// XCD against 4 MB of L2 they are fetched again and again (135 MB counted for a 32 MiB text).
+constexpr int kPreGroups = 5;
+template <int C, bool GUARD, bool CLS, bool HALO, bool PRE = false>
 __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot, const uint8_t *clsmap, uint32_t wt,
     uint32_t lane)
 {
@@ -309,12 +316,43 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 		fb[c] = 0;
 	}
 	const uint32_t groups = (a.S + hb) >> 4;
+	// (five named sets, picked by a branch on the wave-uniform g below: an array of them indexed by g
+	// would live in scratch)
+	uint4 p0[C], p1[C], p2[C], p3[C], p4[C];
+	static_assert(kPreGroups == 5, "five register sets");
+	if (PRE) {
+		auto fetch = [&](int c, uint32_t gi) -> uint4 {
+			const int64_t at = (int64_t)base[c] - hb + (int64_t)gi * 16;
+			if (gi < groups && (!GUARD || (at >= 0 && at < (int64_t)a.n)))
+				return a.text16[at >> 4];
+			return make_uint4(0, 0, 0, 0);
+		};
+#pragma unroll
+		for (int c = 0; c < C; c++) {
+			p0[c] = fetch(c, 0);
+			p1[c] = fetch(c, 1);
+			p2[c] = fetch(c, 2);
+			p3[c] = fetch(c, 3);
+			p4[c] = fetch(c, 4);
+		}
+	}
 	for (uint32_t g = 0; g < groups; g++) {
 		// (prefetching the next group does not help: vector loads return in order, so
 		// the first cold gather of this group would wait for the prefetch anyway)
 		uint4 w[C];
+		if (PRE) {   // (g is wave-uniform: scalar branches, no indexed registers)
+			const uint32_t gu = __builtin_amdgcn_readfirstlane(g);
 #pragma unroll
-		for (int c = 0; c < C; c++) {
+			for (int c = 0; c < C; c++) {
+				if (gu == 0) w[c] = p0[c];
+				else if (gu == 1) w[c] = p1[c];
+				else if (gu == 2) w[c] = p2[c];
+				else if (gu == 3) w[c] = p3[c];
+				else w[c] = p4[c];
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < C && !PRE; c++) {
 			const int64_t at = (int64_t)base[c] - hb + (int64_t)g * 16;   // first byte of the group
 			if (!GUARD || (at >= 0 && at < (int64_t)a.n))
 				w[c] = a.text16[at >> 4];
@@ -400,6 +438,41 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 			walk_tile<C, false, CLS, HALO>(a, hot, clsmap, wt, lane);
 		else
 			walk_tile<C, true, CLS, HALO>(a, hot, clsmap, wt, lane);
+	}
+}
+
+// Halo mode with the text loaded up front (walk_tile, PRE): the registers that takes are there for
+// workgroups of 8 waves; with chains of 64 bytes a 32 MiB text has a tile per wave of them anyway.
+constexpr int kBlockPre = 768;
+template <bool CLS>
+__global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
+	uint8_t *clsmap = (uint8_t *)hot + acm::kHotBytes;
+	if (CLS && threadIdx.x < 64)
+		((uint32_t *)clsmap)[threadIdx.x] = ((const uint32_t *)a.cls)[threadIdx.x];
+	{
+		const uint4 *src = (const uint4 *)a.hot;
+		uint4 *dst = (uint4 *)hot;
+		const uint32_t n16 = ((a.H << a.ls) + 7) >> 3;
+		const uint32_t rot = n16 ? (blockIdx.x * 1021u) % n16 : 0u;
+		for (uint32_t i = threadIdx.x; i < n16; i += kBlockPre) {
+			uint32_t j = i + rot;
+			j = j >= n16 ? j - n16 : j;
+			dst[j] = src[j];
+		}
+	}
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = blockIdx.x * (kBlockPre / 64) + (threadIdx.x >> 6);
+	const uint32_t nwaves = gridDim.x * (kBlockPre / 64);
+	const uint32_t tile_bytes = (4 * 64u) << a.logS;
+	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
+		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n && (uint64_t)wt * tile_bytes >= a.halo_bytes;
+		if (full)
+			walk_tile<4, false, CLS, true, true>(a, hot, clsmap, wt, lane);
+		else
+			walk_tile<4, true, CLS, true, true>(a, hot, clsmap, wt, lane);
 	}
 }
 
@@ -793,7 +866,15 @@ int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
 	if (blocks > (uint32_t)num_cus)
 		blocks = (uint32_t)num_cus;
-	if (a.halo_mode && C == 4) {
+	if (a.halo_mode && C == 4 && a.halo_pre) {
+		uint32_t pblocks = (a.n_tiles + kBlockPre / 64 - 1) / (kBlockPre / 64);
+		if (pblocks > (uint32_t)num_cus)
+			pblocks = (uint32_t)num_cus;
+		if (a.ls == 8)
+			hipLaunchKernelGGL(k_halo_walk<false>, dim3(pblocks), dim3(kBlockPre), lds, s, a);
+		else
+			hipLaunchKernelGGL(k_halo_walk<true>, dim3(pblocks), dim3(kBlockPre), lds, s, a);
+	} else if (a.halo_mode && C == 4) {
 		if (a.ls == 8)
 			hipLaunchKernelGGL((k_spec_walk<4, false, true>), dim3(blocks), dim3(kBlock1), lds, s, a);
 		else
@@ -1024,7 +1105,8 @@ int scan_prepare(const acm_dfa *)
 {
 	const void *walks[] = { (const void *)k_spec_walk<4, false, false>, (const void *)k_spec_walk<4, true, false>,
 		(const void *)k_spec_walk<2, false, false>, (const void *)k_spec_walk<2, true, false>,
-		(const void *)k_spec_walk<4, false, true>, (const void *)k_spec_walk<4, true, true> };
+		(const void *)k_spec_walk<4, false, true>, (const void *)k_spec_walk<4, true, true>,
+		(const void *)k_halo_walk<false>, (const void *)k_halo_walk<true> };
 	for (const void *k : walks)
 		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(acm::kHotBytes + 256)));
 	return ACM_OK;
@@ -1262,6 +1344,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 		const uint32_t hb = ((a.L > 1 ? a.L - 1 : 0u) + 15u) & ~15u;
 		a.halo_mode = (d->use_halo && C == 4 && hb <= S) ? 1u : 0u;
 		a.halo_bytes = a.halo_mode ? hb : 0u;
+		a.halo_pre = (a.halo_mode && ((S + hb) >> 4) <= (uint32_t)kPreGroups && d->use_preload) ? 1u : 0u;
 	}
 	a.drop_before = (uint32_t)halo;
 	a.off_shift = (int32_t)offset_shift;
