@@ -29,6 +29,7 @@ struct acm_dfa {
 
 	// sparse ("sieve") pipeline tables, sieve_tables.h
 	uint32_t sv_stride = 0;              // W: one text position in W is sampled
+	uint32_t sv_gram_len = 3;            // bytes of a sample the filter looks at: 3, or 6 where every pattern has W + 5 bytes
 	uint32_t sv_run_ok[8] = { 0 };       // bit b: D copies of byte b are a trie path
 	uint32_t sv_prefix_len = 0;          // D: bytes of a pattern checked exactly before a follower starts
 	uint32_t *d_sv_bloom = nullptr;      // [1 << sv_bloom_log_words] Bloom filter over the 3-grams at offsets < W, copied to LDS

@@ -130,8 +130,18 @@ int build_sieve(const acm_automaton &a, acm_dfa *d)
 			const uint32_t g = (uint32_t)p.bytes[o] | ((uint32_t)p.bytes[o + 1] << 8) | ((uint32_t)p.bytes[o + 2] << 16);
 			grams[g] |= 1u << o;
 		}
+	// the filter's keys: the 3-grams, or the 6 bytes at the sampled offsets where every pattern has them
+	const uint32_t LG = (W + 5 <= shortest && W >= 4) ? 6u : 3u;
+	d->sv_gram_len = LG;
+	std::unordered_map<uint64_t, bool> fkeys;
+	for (const auto &p : a.patterns)
+		for (uint32_t o = 0; o < W; o++) {
+			const uint64_t g3 = (uint32_t)p.bytes[o] | ((uint32_t)p.bytes[o + 1] << 8) | ((uint32_t)p.bytes[o + 2] << 16);
+			const uint64_t m3 = LG == 6 ? (uint32_t)p.bytes[o + 3] | ((uint32_t)p.bytes[o + 4] << 8) | ((uint32_t)p.bytes[o + 5] << 16) : 0u;
+			fkeys[g3 | (m3 << 24)] = true;
+		}
 	uint32_t lw = acm::kSieveMinLogWords;
-	while (lw < acm::kSieveMaxLogWords && ((size_t)1 << lw) < grams.size())
+	while (lw < acm::kSieveMaxLogWords && ((size_t)1 << lw) < fkeys.size())
 		lw++;
 	if (const char *e = getenv("ACM_BLOOM_LOG_WORDS")) {   // debugging aid
 		const int v = atoi(e);
@@ -140,9 +150,10 @@ int build_sieve(const acm_automaton &a, acm_dfa *d)
 	}
 	d->sv_bloom_log_words = lw;
 	std::vector<uint32_t> bloom((size_t)1 << lw, 0);
-	for (const auto &kv : grams) {
-		const uint32_t blk = acm::sieve_bloom_block(kv.first, lw);
-		const uint64_t bits = acm::sieve_bloom_bits(kv.first);
+	for (const auto &kv : fkeys) {
+		const uint32_t g3 = (uint32_t)(kv.first & 0xFFFFFFu), m3 = (uint32_t)(kv.first >> 24);
+		const uint32_t blk = acm::sieve_bloom_block(g3, m3, lw);
+		const uint64_t bits = acm::sieve_bloom_bits(g3, m3);
 		bloom[2 * blk] |= (uint32_t)bits;
 		bloom[2 * blk + 1] |= (uint32_t)(bits >> 32);
 	}

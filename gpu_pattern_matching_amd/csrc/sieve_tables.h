@@ -44,11 +44,19 @@ ACM_HD uint32_t mul24(uint32_t a, uint32_t b)
 	return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu));
 #endif
 }
+// The key of a sample is its 3-gram, or -- where the shortest pattern has W + 5 bytes, i.e. where
+// the 6 bytes at every sampled offset are pattern bytes -- the 3-gram and the 3 bytes behind it
+// ('more' = those three, 0 otherwise): 48 bits instead of 24 are what keeps the common 3-grams of
+// real binaries out of the check kernel.
+constexpr uint32_t kSieveMulE = 0xB5297Bu, kSieveMulF = 0x68E31Du;
 // block index: log_words counts 32-bit words, a block is two of them
-ACM_HD uint32_t sieve_bloom_block(uint32_t gram, uint32_t log_words) { return mul24(gram, kSieveMulA) >> (33 - log_words); }
-ACM_HD uint64_t sieve_bloom_bits(uint32_t gram)
+ACM_HD uint32_t sieve_bloom_block(uint32_t gram, uint32_t more, uint32_t log_words)
 {
-	const uint32_t p = mul24(gram, kSieveMulB);
+	return (mul24(gram, kSieveMulA) + mul24(more, kSieveMulE)) >> (33 - log_words);
+}
+ACM_HD uint64_t sieve_bloom_bits(uint32_t gram, uint32_t more)
+{
+	const uint32_t p = mul24(gram, kSieveMulB) + mul24(more, kSieveMulF);
 	return (1ull << (p >> 26)) | (1ull << ((p >> 20) & 63)) | (1ull << ((p >> 14) & 63)) | (1ull << ((p >> 8) & 63));
 }
 

@@ -229,13 +229,13 @@ __device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh
 
 // the filter in two halves, so that the reads of many samples can be in flight before the first is
 // looked at: the key's 64-bit block (one ds_read_b64), then its four bits
-__device__ __forceinline__ uint64_t bloom_block(const uint32_t *bloom, uint32_t gram, uint32_t block_shift)
+__device__ __forceinline__ uint64_t bloom_block(const uint32_t *bloom, uint32_t gram, uint32_t more, uint32_t block_shift)
 {
-	return ((const uint64_t *)bloom)[acm::mul24(gram, acm::kSieveMulA) >> block_shift];
+	return ((const uint64_t *)bloom)[(acm::mul24(gram, acm::kSieveMulA) + acm::mul24(more, acm::kSieveMulE)) >> block_shift];
 }
-__device__ __forceinline__ uint32_t bloom_test(uint64_t w, uint32_t gram)
+__device__ __forceinline__ uint32_t bloom_test(uint64_t w, uint32_t gram, uint32_t more)
 {
-	const uint32_t p = acm::mul24(gram, acm::kSieveMulB);
+	const uint32_t p = acm::mul24(gram, acm::kSieveMulB) + acm::mul24(more, acm::kSieveMulF);
 	return (uint32_t)((w >> (p >> 26)) & (w >> ((p >> 20) & 63)) & (w >> ((p >> 14) & 63)) & (w >> ((p >> 8) & 63))) & 1u;
 }
 
@@ -759,7 +759,7 @@ struct BulkBatch {
 	}
 };
 
-template <int W, bool DBG>
+template <int W, bool DBG, int LG>
 __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bloom[];
@@ -773,7 +773,8 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	v4u w[LOADS];
 	uint32_t nx[LOADS];
 	uint32_t present = 0;   // bit j: group j of the sub-block exists for this lane
-	constexpr int PER = W <= 2 ? 2 : 1;   // load instructions per group
+	constexpr bool NEXT = W <= 2 || (LG == 6 && W == 4);   // a sample's key reaches into the next group: 4 more bytes per lane
+	constexpr int PER = NEXT ? 2 : 1;   // load instructions per group
 	// the groups of the sub-block at 'off' of 'tile'.  Always exactly LOADS * PER load instructions,
 	// whatever exists of the tile (what does not exist is read at the start of the text and masked
 	// out): the waits count them.  Plain loads, not non-temporal ones: the check kernel comes back
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 			const bool ok = tile < a.ntiles && rel < a.tile_bytes && g16 < n16;
 			present |= (ok ? 1u : 0u) << j;
 			load16(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
-			if (W <= 2)
+			if (NEXT)
 				load4(nx[j], text32 + (ok && g16 + 1 < n16 ? (size_t)g16 * 4 + 4 : 0));
 			else
 				nx[j] = 0;
@@ -812,6 +813,15 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 		const uint32_t x[5] = { w[j].x, w[j].y, w[j].z, w[j].w, nx[j] };
 		const uint32_t b = k * W, i = b / 4, sh = b % 4;
 		const uint32_t v = sh == 0 ? x[i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i], sh);
+		return v & 0xFFFFFFu;
+	};
+	// the 3 bytes behind the 3-gram (6-byte keys), else 0
+	auto more_of = [&](uint32_t j, uint32_t k) -> uint32_t {
+		if (LG != 6)
+			return 0u;
+		const uint32_t x[5] = { w[j].x, w[j].y, w[j].z, w[j].w, nx[j] };
+		const uint32_t b = k * W + 3, i = b / 4, sh = b % 4;
+		const uint32_t v = sh == 0 ? x[i > 4 ? 4 : i] : __builtin_amdgcn_alignbyte(x[i + 1 > 4 ? 4 : i + 1], x[i > 4 ? 4 : i], sh);
 		return v & 0xFFFFFFu;
 	};
 	const uint32_t tile_first = blockIdx.x * kWaves + wv;
@@ -882,14 +892,14 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 						arrived(j);
 #pragma unroll
 					for (uint32_t i = 0; i < U; i++)
-						blk[u & 1][i] = bloom_block(bloom, gram_of(j, k0 + i), word_shift);
+						blk[u & 1][i] = bloom_block(bloom, gram_of(j, k0 + i), more_of(j, k0 + i), word_shift);
 				}
 				if (u > 0) {
 					const uint32_t v = u - 1, j = v / UPG, k0 = (v % UPG) * U;
 					const uint32_t room = room_of(j);
 #pragma unroll
 					for (uint32_t i = 0; i < U; i++)
-						f |= (bloom_test(blk[v & 1][i], gram_of(j, k0 + i)) & (k0 + i < room ? 1u : 0u)) << (j * S + k0 + i);
+						f |= (bloom_test(blk[v & 1][i], gram_of(j, k0 + i), more_of(j, k0 + i)) & (k0 + i < room ? 1u : 0u)) << (j * S + k0 + i);
 				}
 				// (an accumulated flag word nobody looks at before the end would let the compiler sink all the
 				// bit tests behind the last read, the blocks of the whole sub-block live until then)
@@ -1300,9 +1310,10 @@ size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
 int sparse_prepare(const acm_dfa *)
 {
 	const int lds = (int)((1u << acm::kSieveMaxLogWords) * 4);
-	const void *kernels[] = { (const void *)k_sieve<8, false>, (const void *)k_sieve<4, false>, (const void *)k_sieve<2, false>,
-		(const void *)k_sieve<1, false>, (const void *)k_sieve<8, true>, (const void *)k_sieve<4, true>,
-		(const void *)k_sieve<2, true>, (const void *)k_sieve<1, true> };
+	const void *kernels[] = { (const void *)k_sieve<8, false, 3>, (const void *)k_sieve<4, false, 3>, (const void *)k_sieve<2, false, 3>,
+		(const void *)k_sieve<1, false, 3>, (const void *)k_sieve<8, true, 3>, (const void *)k_sieve<4, true, 3>,
+		(const void *)k_sieve<2, true, 3>, (const void *)k_sieve<1, true, 3>, (const void *)k_sieve<8, false, 6>,
+		(const void *)k_sieve<4, false, 6>, (const void *)k_sieve<8, true, 6>, (const void *)k_sieve<4, true, 6> };
 	for (const void *k : kernels)
 		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 	return ACM_OK;
@@ -1420,19 +1431,32 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
 	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)
 		eblocks *= 2;
+	const bool long_keys = d->sv_gram_len == 6;
 	if (!want_stamps) {
 		switch (d->sv_stride) {
-		case 8: hipLaunchKernelGGL((k_sieve<8, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		case 4: hipLaunchKernelGGL((k_sieve<4, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		case 2: hipLaunchKernelGGL((k_sieve<2, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		default: hipLaunchKernelGGL((k_sieve<1, false>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 8:
+			if (long_keys) hipLaunchKernelGGL((k_sieve<8, false, 6>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			else hipLaunchKernelGGL((k_sieve<8, false, 3>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			break;
+		case 4:
+			if (long_keys) hipLaunchKernelGGL((k_sieve<4, false, 6>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			else hipLaunchKernelGGL((k_sieve<4, false, 3>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, false, 3>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		default: hipLaunchKernelGGL((k_sieve<1, false, 3>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
 		}
 	} else {   // debugging aid: the same kernel with clock stamps
 		switch (d->sv_stride) {
-		case 8: hipLaunchKernelGGL((k_sieve<8, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		case 4: hipLaunchKernelGGL((k_sieve<4, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		case 2: hipLaunchKernelGGL((k_sieve<2, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
-		default: hipLaunchKernelGGL((k_sieve<1, true>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		case 8:
+			if (long_keys) hipLaunchKernelGGL((k_sieve<8, true, 6>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			else hipLaunchKernelGGL((k_sieve<8, true, 3>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			break;
+		case 4:
+			if (long_keys) hipLaunchKernelGGL((k_sieve<4, true, 6>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			else hipLaunchKernelGGL((k_sieve<4, true, 3>), dim3(blocks), dim3(kBlock), lds, s, grp);
+			break;
+		case 2: hipLaunchKernelGGL((k_sieve<2, true, 3>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
+		default: hipLaunchKernelGGL((k_sieve<1, true, 3>), dim3(blocks), dim3(kBlock), lds, s, grp); break;
 		}
 	}
 	if (after_sieve)

@@ -389,6 +389,31 @@ def test_auto_mode_counts_sample_heavy_batches(gpu):
     m.close()
 
 
+@pytest.mark.parametrize("shortest", [9, 13])
+def test_six_byte_filter_keys(gpu, shortest):
+    """Where every pattern has W + 5 bytes the filter looks at 6 bytes of a sample instead of 3 (shortest
+    pattern 9: stride 4; 13: stride 8).  Same planes as the oracle's, on text with signatures planted
+    whole, cut at either end, and sharing their first bytes."""
+    allp = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 1200)
+    pats = [p[:shortest + (i % 40)] for i, p in enumerate(allp) if len(p) >= shortest + 40]
+    pats = list(dict.fromkeys(pats))[:600]
+    assert min(len(p) for p in pats) == shortest
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 21)
+    assert m.set_mode("sparse") == "sparse"
+    rng = np.random.default_rng(shortest)
+    for n in (4096, 100003, (1 << 21) - 5):
+        text = rng.integers(0, 256, size=n, dtype=np.uint8)
+        for _ in range(n // 300):
+            p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+            cut = int(rng.integers(0, 3))
+            piece = p if cut == 0 else p[:max(3, p.size - int(rng.integers(1, 6)))] if cut == 1 else p[int(rng.integers(1, 4)):]
+            at = int(rng.integers(0, max(1, n - piece.size)))
+            text[at:at + piece.size] = piece[:n - at]
+        assert_same(m.scan(text), o.scan(text))
+    m.close()
+
+
 def test_real_binary_content(gpu):
     """Not synthetic: 48 MiB out of the middle of the largest ROCm library on the box (code, zero
     pages, tables, strings) x 2000 and 15000 signatures.  Whatever path the data makes the sparse
