@@ -916,24 +916,32 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 					if (!__ballot(fj != 0))
 						continue;
 					{
-						// Runs (zero pages, padding): a lane whose 16 bytes are one byte b, between two lanes
-						// that hold the same, sees nothing but b in every window a candidate of its samples
-						// could start in ([p - W + 1, p + D), D <= 10) -- unless D copies of b are a trie path,
-						// none of them is a pattern's prefix, and the check kernel is spared a tile full of
-						// samples.
+						// Runs (zero pages, padding, zero-filled fields): every window a candidate of sample p
+						// could start in lies in [p - W + 1, p + D), D <= 10.  If all of that is one byte b -- the
+						// lane's own 16 bytes, and where the range leaves them the tail of the lane in front or the
+						// head of the lane behind -- then unless D copies of b are a trie path none of the windows
+						// is a pattern's prefix, and the check kernel is spared the sample.
 						const uint32_t x = w[j].x;
 						if (__ballot(fj != 0 && w[j].y == x)) {   // (one compare decides it on any text without runs)
 							const bool same = w[j].y == x && w[j].z == x && w[j].w == x && __builtin_amdgcn_alignbyte(x, x, 1) == x;
-							const unsigned long long sm = __ballot(same);
-							const uint32_t xl = __shfl_up(x, 1, 64), xr = __shfl_down(x, 1, 64);
+							const uint32_t pz = __shfl_up(w[j].z, 1, 64), pw = __shfl_up(w[j].w, 1, 64);
+							const uint32_t nx0 = __shfl_down(w[j].x, 1, 64), nx1 = __shfl_down(w[j].y, 1, 64);
+							const bool left = lane > 0 && pz == x && pw == x;          // the 8 bytes in front of the lane's
+							const bool right4 = lane < 63 && nx0 == x, right8 = right4 && nx1 == x;   // the 4 / 8 bytes behind them
 							const uint32_t b = x & 0xFFu, wi = b >> 5;
 							uint32_t word = g.common.run_ok[0];
 #pragma unroll
 							for (uint32_t i = 1; i < 8; i++)
 								word = wi == i ? g.common.run_ok[i] : word;
-							const bool inner = lane > 0 && lane < 63 && ((sm >> (lane - 1)) & 5ull) == 5ull && xl == x && xr == x;
-							if (same && inner && !((word >> (b & 31u)) & 1u))
-								fj = 0;
+							if (same && !((word >> (b & 31u)) & 1u)) {
+#pragma unroll
+								for (uint32_t k = 0; k < S; k++) {
+									const bool lok = k * W >= W - 1 || left;
+									const bool rok = k * W + 10 <= 16 || (k * W + 10 <= 20 ? right4 : right8);
+									if (lok && rok)
+										fj &= ~(1u << k);
+								}
+							}
 						}
 					}
 					if (!__ballot(fj != 0))
