@@ -224,21 +224,25 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
 
     Geff = G if args.issue != "main" else 1
 
-    def timed(i):
-        """is worker 0's i-th step of a block one whose kernels are timed?  Whole launch groups, every
-        pe-th of them."""
-        return (i // Geff) % pe == 0
+    # The steps are dealt to the workers a launch group at a time: steps 0 .. Geff-1 to worker 0, the next
+    # Geff to worker 1, ...  (a short block then ends with ONE short group, not with one per worker)
+    def worker_of(k):
+        return (k // Geff) % W
 
-    timed_steps = sum(1 for i in range(len(range(0, K, W))) if timed(i))
+    def timed(k):
+        """is step k one of worker 0's whose kernels are timed?  Whole launch groups, every pe-th of them."""
+        return worker_of(k) == 0 and (k // (Geff * W)) % pe == 0
+
+    timed_steps = sum(1 for k in range(K) if timed(k))
 
     def batches(profile):
         out = []
         for k in range(K):
-            w, p = k % W, planes[k % slots]
+            w, p = worker_of(k), planes[k % slots]
             out.append(matcher.make_batch(d_texts[k % ntexts], n_local, streams[w].cuda_stream, p[0], p[1], cap,
-                                          (wss[w][(k // W) % G], ws_bytes), halo=plan["halo"],
+                                          (wss[w][k % G], ws_bytes), halo=plan["halo"],
                                           offset_shift=plan["offset_shift"],
-                                          profile=profile and w == 0 and timed(k // W)))
+                                          profile=profile and timed(k)))
         return out
 
     plain, profiled = batches(False), batches(True)
@@ -247,18 +251,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     enq, enq_many = matcher.lib.acm_scan_batch_async, matcher.lib.acm_scan_batches_async
     dfa = matcher.dfa
     Batch = type(plain[0])
-    # the steps of a block as arrays for acm_scan_batches_async: all of them in step order (native),
-    # or worker w's share (threads)
-    # (native: a worker's steps G at a time, the workers in turn -- consecutive entries on one stream
-    # are what the library groups)
-    def native_order(count, lo=0):
-        per = [[k for k in range(lo, count) if k % W == w] for w in range(W)]
-        out, r = [], 0
-        while any(r * Geff < len(p) for p in per):
-            for p in per:
-                out.extend(p[r * Geff:(r + 1) * Geff])
-            r += 1
-        return out
+    # the steps of a block as arrays for acm_scan_batches_async: all of them in step order (native:
+    # consecutive entries on one stream are what the library groups), or worker w's share (threads)
 
     # N > 1: a block's planes go to rank 0 in up to three gathers, each behind the scans it carries and
     # beside the scans of the next piece (a piece = whole rounds of launch groups: a contiguous range of
@@ -274,19 +268,20 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 lo = hi
         return out
 
-    whole = {(id(bs), c): (Batch * c)(*[bs[k] for k in native_order(c)])
-             for bs in (plain, profiled) for c in {K, min(K, max(warmup, W))}}
+    whole = {(id(bs), c): (Batch * c)(*bs[:c]) for bs in (plain, profiled) for c in {K, min(K, max(warmup, W))}}
     chunked = native and dist.is_initialized() and slots == K
-    piecewise = {id(bs): [(lo, hi, (Batch * (hi - lo))(*[bs[k] for k in native_order(hi, lo)])) for lo, hi in pieces(K)]
+    piecewise = {id(bs): [(lo, hi, (Batch * (hi - lo))(*bs[lo:hi])) for lo, hi in pieces(K)]
                  for bs in (plain, profiled)} if chunked else {}
-    share = {id(bs): [(Batch * len(bs[w::W]))(*bs[w::W]) for w in range(W)] for bs in (plain, profiled)}
+    mine_of = [[k for k in range(K) if worker_of(k) == w] for w in range(W)]
+    share = {id(bs): [(Batch * max(1, len(mine_of[w])))(*[bs[k] for k in mine_of[w]]) for w in range(W)]
+             for bs in (plain, profiled)}
 
     def issue(bs, count):
-        """count steps, step k on worker (stream) k % W.  threads: every worker's steps are enqueued by
+        """count steps, step k on worker (stream) worker_of(k).  threads: every worker's steps are enqueued by
         its own host thread with one acm_scan_batches_async call; native: one call from this thread
         enqueues them all in step order; main: this thread, one FFI call per step."""
         def job(w):
-            mine = len(range(w, count, W))
+            mine = sum(1 for k in mine_of[w] if k < count)
             rc = enq_many(dfa, share[id(bs)][w], mine) if mine else 0
             if rc:
                 check(rc, "acm_scan_batches_async")
