@@ -375,7 +375,6 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 		for (int c = 0; c < C; c++) {
 			if (chain[c] < a.n_chains) {
 				a.cnt[chain[c]] = (int32_t)cnt[c];
-				a.k2info[chain[c]] = 0;
 				total += cnt[c];
 				if (chain[c] == a.n_chains - 1)
 					a.misc[0] = st[c];   // the state after the last byte
@@ -765,7 +764,7 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 			const uint32_t pos = rec.x, st = rec.y & 0xFFFFFFu, seq = rec.y >> 24;
 			const uint32_t jj = pos >> a.logS;
 			uint32_t d = off[jj - j0] + seq;
-			if (from_k1) {
+			if (from_k1 && !a.halo_mode) {   // (halo mode: nothing is ever dropped or staged by a resolve kernel)
 				const uint32_t info = a.k2info[jj];
 				if (info & 0x10000u)
 					continue;
