@@ -514,3 +514,27 @@ def test_grouped_batches(gpu, group):
         got = _planes(planes2[k][0], planes2[k][1], cap, m.stream)
         assert_same(got, o.scan(texts[k % nb], init_state=inits[k % nb]))
     m.close()
+
+
+def test_grouped_batches_large_tiles(gpu):
+    """A launch group of texts large enough for tiles of several sub-blocks (40 MiB + 3: 16 KiB tiles, the
+    bulk kernel's waves go through two sub-blocks per tile and ten tiles per batch), length not a
+    multiple of 16."""
+    pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 2000)
+    a, o = build(pats)
+    n = (40 << 20) + 3
+    m = Matcher(a, 0, max_text=n)
+    assert m.set_mode("sparse") == "sparse"
+    ws_bytes = m.lib.acm_scan_workspace_bytes(m.dfa, n)
+    cap = 1 << 14
+    texts = [synth.clamav_corpus(n, 40 + k, pats, 3000) for k in range(3)]
+    long_one = next(q for q in pats if len(q) >= 60)
+    texts[1][n - 40:] = np.frombuffer(long_one, dtype=np.uint8)[:40]      # a signature cut by the end of the text
+    d_texts = [DeviceArray.from_numpy(t) for t in texts]
+    wss = [DeviceArray(ws_bytes) for _ in range(3)]
+    planes = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(3)]
+    m.enqueue_many([m.make_batch(d_texts[k], n, m.stream, planes[k][0], planes[k][1], cap, (wss[k], ws_bytes))
+                    for k in range(3)])
+    for k in range(3):
+        assert_same(_planes(planes[k][0], planes[k][1], cap, m.stream), o.scan(texts[k]))
+    m.close()
