@@ -538,3 +538,33 @@ def test_grouped_batches_large_tiles(gpu):
     for k in range(3):
         assert_same(_planes(planes[k][0], planes[k][1], cap, m.stream), o.scan(texts[k]))
     m.close()
+
+
+def test_grouped_batches_mixed_reports(gpu):
+    """The batches of a launch group keep what is theirs: one reports pattern indices, its neighbour --
+    same text -- the final states (all-patterns reporting); offsets agree, the state plane is that of a
+    scan enqueued alone."""
+    from gpu_pattern_matching_amd import _lib
+    pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 500)
+    a, o = build(pats)
+    n = 1 << 20
+    text = synth.clamav_corpus(n, 3, pats, 400)
+    m = Matcher(a, 0, max_text=n)
+    assert m.set_mode("sparse") == "sparse"
+    ws_bytes = m.lib.acm_scan_workspace_bytes(m.dfa, n)
+    cap = 1 << 12
+    d = DeviceArray.from_numpy(text)
+    wss = [DeviceArray(ws_bytes) for _ in range(3)]
+    planes = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(3)]
+    alone = m.make_batch(d, n, m.stream, planes[2][0], planes[2][1], cap, (wss[2], ws_bytes), report=_lib.REPORT_STATE)
+    m.enqueue(alone)
+    want_states = _planes(planes[2][0], planes[2][1], cap, m.stream)
+    m.enqueue_many([m.make_batch(d, n, m.stream, planes[0][0], planes[0][1], cap, (wss[0], ws_bytes)),
+                    m.make_batch(d, n, m.stream, planes[1][0], planes[1][1], cap, (wss[1], ws_bytes),
+                                 report=_lib.REPORT_STATE)])
+    heads = _planes(planes[0][0], planes[0][1], cap, m.stream)
+    states = _planes(planes[1][0], planes[1][1], cap, m.stream)
+    assert_same(heads, o.scan(text))
+    assert np.array_equal(states[0], heads[0]) and states[2] == heads[2]
+    assert np.array_equal(states[1], want_states[1]) and not np.array_equal(states[1], heads[1])
+    m.close()
