@@ -357,6 +357,19 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     elapsed = statistics.median(blocks)
     host_planes = planes.cpu().numpy()      # the planes of the last timed block
     gathered_host = [g.cpu().numpy() for g in gathered] if gathered is not None else None
+    # the same block with a set of launches per step (no launch groups), for comparison: three blocks
+    ungrouped = None
+    if headline and world == 1 and Geff > 1 and matcher.sparse_eligible() and args.mode != "chain":
+        matcher.lib.acm_scan_set_max_group(matcher.dfa, 1)
+        ub = []
+        for rep in range(3):
+            fence()
+            t0 = time.perf_counter()
+            block(plain)
+            fence()
+            ub.append(time.perf_counter() - t0)
+        matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
+        ungrouped = statistics.median(ub)
     # one batch in flight (outside the timed region): what the kernels take when they have the GPU
     # to themselves
     scratch = torch.zeros((2, cap), dtype=torch.int32, device=dev)
@@ -547,6 +560,12 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "frac": round(alg_batch * Geff / gk / 1e9 / HBM_PEAK_GBS, 5),
                 "launches": g_n,
             }
+        if ungrouped is not None:
+            out["one_launch_set_per_step"] = {
+                "value": round(total_bytes * K / ungrouped / 1e9, 3), "unit": "GB/s",
+                "ms_per_step": round(ungrouped / K * 1e3, 5),
+                "what": "the same block with acm_scan_set_max_group(1): three kernel launches per step instead of per "
+                        "group of up to %d steps" % G}
         if e2e is not None:
             out["e2e_with_h2d"] = e2e
         if cpu is not None:
