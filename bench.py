@@ -172,10 +172,12 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     log(rank, "%s: %d states, L=%d, compile %.2fs, device %.1f MB, sparse eligible: %s" % (
         wl.name, states, L, t_compile, matcher.device_bytes / 1e6, matcher.sparse_eligible()))
     if workers <= 0:
-        # automatic: the sparse pipeline's batches go eight to a launch, four streams of such groups keep
-        # the bulk kernel busy (4.4-4.5 against 4.1-4.2 TB/s with three; 20-step blocks the same); the chain
-        # pipeline's walk kernel fills the device by itself, three are enough
-        workers = 4 if (matcher.sparse_eligible() and args.mode != "chain") else 3
+        # automatic: three.  The sparse pipeline's batches go eight to a launch and three streams of such
+        # groups keep the bulk kernel busy; a fourth adds 3-5 % on long blocks (4.3-4.5 against 4.1-4.3 TB/s),
+        # nothing on 20-step blocks, and costs 50-step blocks 4 % -- and the bulk kernels of the streams queue
+        # behind each other, so every launch then takes a third longer from dispatch to end.  The chain
+        # pipeline's walk kernel fills the device by itself.
+        workers = 3
 
     # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
     #      loads its range plus the halo in front of it -------------------------------------------
@@ -588,7 +590,7 @@ def main():
     ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=0,
-                    help="HIP streams the steps are dealt over (0: automatic: 4 for the sparse pipeline, 3 for chain)")
+                    help="HIP streams the steps are dealt over (0: automatic = 3)")
     ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
     ap.add_argument("--group", type=int, default=8,
                     help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..8")
