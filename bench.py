@@ -361,7 +361,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     gathered_host = [g.cpu().numpy() for g in gathered] if gathered is not None else None
     # the same block with a set of launches per step (no launch groups), for comparison: three blocks
     ungrouped = None
-    if headline and world == 1 and Geff > 1 and matcher.sparse_eligible() and args.mode != "chain":
+    if headline and world == 1 and Geff > 1 and matcher.sparse_eligible() and args.mode != "chain" and not args.no_extra:
         matcher.lib.acm_scan_set_max_group(matcher.dfa, 1)
         ub = []
         for rep in range(3):
@@ -375,7 +375,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     # one batch in flight (outside the timed region): what the kernels take when they have the GPU
     # to themselves
     scratch = torch.zeros((2, cap), dtype=torch.int32, device=dev)
-    for i in range(12):
+    for i in range(0 if args.no_extra else 12):
         matcher.enqueue(matcher.make_batch(d_texts[i % ntexts], n_local, streams[0].cuda_stream, scratch[0], scratch[1],
                                            cap, (wss[0][0], ws_bytes), halo=plan["halo"],
                                            offset_shift=plan["offset_shift"], profile=True))
@@ -384,7 +384,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     # ... and one launch group of Geff batches in flight, alone
     g_k1 = g_k2 = g_pipe = 0.0
     g_n = 0
-    if Geff > 1:
+    if Geff > 1 and not args.no_extra:
         gsc = torch.zeros((Geff, 2, cap), dtype=torch.int32, device=dev)
         for i in range(6):
             matcher.enqueue_many([matcher.make_batch(d_texts[(i * Geff + j) % ntexts], n_local, streams[0].cuda_stream,
@@ -606,6 +606,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="only the warm-up and the timed blocks: no one-batch / one-group / ungrouped side measurements "
+                         "(for a profiler run whose per-kernel averages should be those of the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
