@@ -214,7 +214,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     streams = [torch.cuda.Stream(device=dev) for _ in range(W)]
     # a worker's consecutive steps alternate between G workspaces: acm_scan_batches_async then puts
     # up to G of them into one set of launches (--group 1: every step has its own three launches)
-    G = max(1, min(args.group, 8))
+    G = max(1, min(args.group, 16))
     G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
     wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
     # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
@@ -592,8 +592,8 @@ def main():
     ap.add_argument("--workers", type=int, default=0,
                     help="HIP streams the steps are dealt over (0: automatic = 3)")
     ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
-    ap.add_argument("--group", type=int, default=8,
-                    help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..8")
+    ap.add_argument("--group", type=int, default=16,
+                    help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..16")
     ap.add_argument("--issue", default="native", choices=["native", "threads", "main"],
                     help="who enqueues the steps of a block: one acm_scan_batches_async call from the main thread, one "
                          "host thread per worker (each with one such call), or the main thread step by step")

@@ -80,7 +80,7 @@ struct acm_dfa {
 	static constexpr size_t kMaxGraphs = 32;
 	bool use_preload = true;             // halo mode: k_halo_walk (text loaded up front) where the chains are short enough
 	bool use_halo = true;                // chain pipeline: halo mode where the longest pattern fits a chain (scan.hip)
-	int max_group = 8;                   // batches acm_scan_batches_async puts into one set of sparse launches
+	int max_group = 16;                   // batches acm_scan_batches_async puts into one set of sparse launches
 	mutable bool use_graphs = false;     // opt-in: measured neutral on this stack
 	mutable std::vector<GraphEntry> graphs;
 	mutable std::vector<void *> parked_graphs;   // evicted execs, destroyed by acm_dfa_release

@@ -1041,14 +1041,14 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 		return ACM_OK;
 	}
 	const uint32_t cap = std::min<uint32_t>((uint32_t)d->max_group, acm::sparse_max_group());
-	const acm_scan_batch *group[16];
+	const acm_scan_batch *group[32];
 	uint32_t m = 0;
 	auto flush = [&]() -> int {
 		int rc = ACM_OK;
 		if (m == 1) {
 			rc = enqueue_batch(d, group[0], true, nullptr);
 		} else if (m > 1) {
-			acm::SieveJob jobs[16];
+			acm::SieveJob jobs[32];
 			for (uint32_t i = 0; i < m && rc == ACM_OK; i++)
 				rc = enqueue_batch(d, group[i], true, &jobs[i]);
 			hipStream_t gs = (hipStream_t)group[0]->stream;

@@ -61,7 +61,7 @@
 // A text that is dense in matches, or in 3-grams of the pattern set that are no pattern
 // prefixes (real binaries), is merely slow here -- the emit kernel counts such batches and
 // AUTO mode moves to the chain pipeline of scan.hip (pick_sparse).
-// A launch may carry up to eight batches of one size (SieveGroup, acm_scan_batches_async):
+// A launch may carry up to sixteen batches of one size (SieveGroup, acm_scan_batches_async):
 // the kernels' fixed costs are then paid once for all of them.
 #include <hip/hip_runtime.h>
 
@@ -141,12 +141,12 @@ struct SieveArgs {
 	uint32_t plane_capacity;
 };
 
-// A launch takes up to kMaxGroup (8) batches of the same size (acm_scan_batches_async): the bulk
+// A launch takes up to kMaxGroup (16) batches of the same size (acm_scan_batches_async): the bulk
 // kernel's waves go through the tiles of one batch after the other, the check and emit kernels
 // get a share of workgroups per batch.  The kernels' fixed costs -- launch, filter fill, the
 // chains of dependent loads of the check kernel -- are paid once per group instead of once
 // per batch.
-constexpr uint32_t kMaxGroup = 8;
+constexpr uint32_t kMaxGroup = 16;
 // What travels in the argument buffer: the tables and the geometry once (a group's batches have
 // one size), 64 bytes per batch; a kernel puts the SieveArgs of its batch together from both (the
 // fields it does not use cost nothing).  An argument buffer of 4 x SieveArgs -- 1.2 KB -- made

@@ -237,7 +237,7 @@ int acm_scan_batch_async(const acm_dfa *, const acm_scan_batch *);
  * visible in stream order when the group's last kernel has run.  Batches that
  * share a workspace are never grouped. */
 int acm_scan_batches_async(const acm_dfa *, const acm_scan_batch *batches, size_t count);
-/* batches per group, 1 (never group) .. 8 (the default).  Returns the value in use;
+/* batches per group, 1 (never group) .. 16 (the default).  Returns the value in use;
  * 0 or negative only queries. */
 int acm_scan_set_max_group(acm_dfa *, int batches);
 

@@ -457,7 +457,7 @@ def _planes(pat, off, cap, stream=None):
     return o[1:1 + m].astype(np.uint32), p[1:1 + m].copy(), int(p[m + 1])
 
 
-@pytest.mark.parametrize("group", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 8, 16])
 def test_grouped_batches(gpu, group):
     """acm_scan_batches_async puts consecutive sparse batches of one size into one set of launches:
     the planes of every batch are those of scanning it alone -- different texts, different carried-in
@@ -504,13 +504,13 @@ def test_grouped_batches(gpu, group):
                 keep = epos >= 64
                 epos, epat = epos[keep] + 1000, epat[keep]
             assert_same(got, (epos, epat, elast))
-    # a run of nine batches that can all share launches: one full group and a rest
-    wss2 = [DeviceArray(ws_bytes) for _ in range(9)]
-    planes2 = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(9)]
+    # a run of seventeen batches that can all share launches: full groups and a rest
+    wss2 = [DeviceArray(ws_bytes) for _ in range(17)]
+    planes2 = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(17)]
     run = [m.make_batch(d_texts[k % nb], n, m.stream, planes2[k][0], planes2[k][1], cap, (wss2[k], ws_bytes),
-                        init_state=inits[k % nb]) for k in range(9)]
+                        init_state=inits[k % nb]) for k in range(17)]
     m.enqueue_many(run)
-    for k in range(9):
+    for k in range(17):
         got = _planes(planes2[k][0], planes2[k][1], cap, m.stream)
         assert_same(got, o.scan(texts[k % nb], init_state=inits[k % nb]))
     m.close()
