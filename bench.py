@@ -217,20 +217,30 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     G = max(1, min(args.group, 16))
     G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
     wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
-    # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
-    # the check, else a ring of slots per worker
-    slots = K if (world > 1 or K * cap * 8 <= (512 << 20)) else min(K, max(W * 2, ntexts))
-    planes = torch.zeros((slots, 2, cap), dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(planes) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_stream = torch.cuda.Stream(device=dev)
     pe = max(1, args.profile_every)
-
     Geff = G if args.issue != "main" else 1
 
     # The steps are dealt to the workers a launch group at a time: steps 0 .. Geff-1 to worker 0, the next
     # Geff to worker 1, ...  (a short block then ends with ONE short group, not with one per worker)
     def worker_of(k):
         return (k // Geff) % W
+
+    # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
+    # the check, else a ring of R slots PER WORKER (two streams never write one slot; the slots of a
+    # launch group are distinct; the last ntexts steps of a block -- the ones that get checked -- survive)
+    R = max(Geff, ntexts, 2)
+    ring = not (world > 1 or K * cap * 8 <= (512 << 20)) and W * R < K
+    slots = W * R if ring else K
+
+    def slot_of(k):
+        if not ring:
+            return k
+        local = (k // (Geff * W)) * Geff + k % Geff      # the step's number among its worker's
+        return worker_of(k) * R + local % R
+
+    planes = torch.zeros((slots, 2, cap), dtype=torch.int32, device=dev)
+    gathered = [torch.empty_like(planes) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_stream = torch.cuda.Stream(device=dev)
 
     def timed(k):
         """is step k one of worker 0's whose kernels are timed?  Whole launch groups, every pe-th of them."""
@@ -241,7 +251,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     def batches(profile):
         out = []
         for k in range(K):
-            w, p = worker_of(k), planes[k % slots]
+            w, p = worker_of(k), planes[slot_of(k)]
             out.append(matcher.make_batch(d_texts[k % ntexts], n_local, streams[w].cuda_stream, p[0], p[1], cap,
                                           (wss[w][k % G], ws_bytes), halo=plan["halo"],
                                           offset_shift=plan["offset_shift"],
@@ -272,7 +282,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         return out
 
     whole = {(id(bs), c): (Batch * c)(*bs[:c]) for bs in (plain, profiled) for c in {K, min(K, max(warmup, W))}}
-    chunked = native and dist.is_initialized() and slots == K
+    chunked = native and dist.is_initialized() and not ring
     piecewise = {id(bs): [(lo, hi, (Batch * (hi - lo))(*bs[lo:hi])) for lo, hi in pieces(K)]
                  for bs in (plain, profiled)} if chunked else {}
     mine_of = [[k for k in range(K) if worker_of(k) == w] for w in range(W)]
@@ -423,8 +433,9 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                "what": "pinned host buffer -> hipMemcpyAsync -> scan, %d streams; PCIe included, file I/O not" % We}
 
     # ---- parity: the planes of the last steps of the last block, every distinct text once -----------
-    last_k = [k for k in range(max(0, K - ntexts), K) if slots == K or k >= K - slots]
-    m_local = int(host_planes[(K - 1) % slots, 0, 0])
+    owner = {slot_of(k): k for k in range(K)}            # the last step that wrote each slot
+    last_k = [k for k in range(max(0, K - ntexts), K) if owner[slot_of(k)] == k]
+    m_local = int(host_planes[slot_of(K - 1), 0, 0])
     m_total = m_local
     if world > 1:
         t = torch.tensor([m_local], dtype=torch.int64, device=red)
@@ -438,9 +449,9 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 ok, nrec = True, 0
                 for k in last_k:
                     if gathered_host is not None:
-                        offs, pids, last_state = sharding.merge_gathered([g[k % slots] for g in gathered_host])
+                        offs, pids, last_state = sharding.merge_gathered([g[slot_of(k)] for g in gathered_host])
                     else:
-                        offs, pids, last_state = sharding.merge_gathered([host_planes[k % slots]])
+                        offs, pids, last_state = sharding.merge_gathered([host_planes[slot_of(k)]])
                     epos, epat, elast = o.scan(logical(k % ntexts), cap=max(cap * world, 1 << 16))
                     good = np.array_equal(epos, offs) and np.array_equal(epat, pids) and elast == last_state
                     if not good:
