@@ -547,7 +547,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "launches_timed": launches,
                 "stage_traffic": stage_traffic or None,
                 "note": "HIP events on the worker's own stream around the kernels of every %d-th launch group of worker 0 "
-                        "in the last timed block; with %d workers a kernel shares the GPU with the other workers' "
+                        "in the last timed block (1: all of them); with %d workers a kernel shares the GPU with the other workers' "
                         "kernels.  traffic = the bulk kernel's counted HBM bytes for ONE batch (profiles/, collected "
                         "with --group 1) x batches_per_launch; stage_traffic: per batch" % (pe, W),
             },
@@ -612,8 +612,8 @@ def main():
                     help="scan pipeline (acm_scan_set_mode); auto = sparse when every signature has >= 3 bytes")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: 32 MiB per GPU (weak) or one 32 MiB text cut N ways (strong)")
-    ap.add_argument("--profile-every", type=int, default=4,
-                    help="HIP events around the kernels of every K-th step of worker 0 in the last timed block")
+    ap.add_argument("--profile-every", type=int, default=1,
+                    help="HIP events around the kernels of every K-th launch group (or step) of worker 0 in the last timed block")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
