@@ -15,8 +15,8 @@ the steps of a block are dealt over --workers HIP streams with private scratch a
 the library with one acm_scan_batches_async call (--issue threads: one call per stream, from a
 host thread each); the library puts up to --group consecutive sparse batches of a stream into
 one set of kernel launches (--group 1: a set of launches per step).  The steps rotate over
---texts distinct 32 MiB texts (more than the 256 MiB Infinity Cache in total), so the text a
-step reads comes from HBM.  The timed region is --repeats blocks of --steps steps, each block
+--texts distinct 32 MiB texts (64 = 2 GiB by default: eight times the 256 MiB Infinity Cache, so
+that with every batch in flight the text a step reads comes from HBM -- sub-records included).  The timed region is --repeats blocks of --steps steps, each block
 bracketed by a barrier + device synchronisation; the line reports the median block.
 
 With N > 1 GPUs the logical text of a step is N x 32 MiB (weak scaling) or one 32 MiB text cut
@@ -181,8 +181,19 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
 
     # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
     #      loads its range plus the halo in front of it -------------------------------------------
+    # ntexts distinct texts (2 GiB at the default of 64: a text's next use is far beyond the 256 MiB
+    # Infinity Cache, whatever the number of batches in flight).  The word corpus is slow to generate, so
+    # beyond `unique` base texts the rest are the base texts rotated by a large odd number of bytes:
+    # different content at every address, checked against the oracle like any other text.
+    unique = ntexts if wl.pats is not None else min(ntexts, 8)
+    base_cache = {}
+
     def shard(i, r):
-        return wl.text(7 + i * 64 + r)
+        b, turn = i % unique, i // unique
+        if (b, r) not in base_cache:
+            base_cache[(b, r)] = wl.text(7 + b * 64 + r)
+        t = base_cache[(b, r)]
+        return t if turn == 0 else np.roll(t, turn * 1048583)
 
     def logical(i):
         return shard(i, 0) if (world == 1 or strong) else np.concatenate([shard(i, r) for r in range(world)])
@@ -204,8 +215,12 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         d_texts.append(t)
         if i < 2:
             h_texts.append(mine)
-    residency = "HBM" if ntexts * n_local > L3_BYTES else "Infinity Cache (%d MiB of texts <= 256 MiB)" % (
-        ntexts * n_local >> 20)
+    if ntexts > 16:
+        base_cache.clear()       # (regenerated for the texts the check looks at)
+    # a text is read again after ntexts - 1 others: HBM only if that is well beyond the Infinity Cache
+    residency = ("HBM (%d MiB of texts = %.1f x the Infinity Cache)" % (ntexts * n_local >> 20, ntexts * n_local / L3_BYTES)
+                 if ntexts * n_local >= 4 * L3_BYTES else
+                 "Infinity Cache in part or whole (%d MiB of texts < 4 x 256 MiB)" % (ntexts * n_local >> 20))
 
     ws_bytes = matcher.lib.acm_scan_workspace_bytes(matcher.dfa, n_local)
     cap = wl.cap
@@ -218,7 +233,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
     wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
     pe = max(1, args.profile_every)
-    Geff = G if args.issue != "main" else 1
+    # launch groups exist for the sparse pipeline only: a workload that runs the chain pipeline is dealt to
+    # the workers step by step (else a 20-step block would put 16 consecutive steps on one stream)
+    groups_apply = matcher.sparse_eligible() and args.mode != "chain"
+    Geff = G if (args.issue != "main" and groups_apply) else 1
 
     # The steps are dealt to the workers a launch group at a time: steps 0 .. Geff-1 to worker 0, the next
     # Geff to worker 1, ...  (a short block then ends with ONE short group, not with one per worker)
@@ -227,8 +245,9 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
 
     # planes of every step of a block: [K, 2, cap] when they all have to survive until the gather /
     # the check, else a ring of R slots PER WORKER (two streams never write one slot; the slots of a
-    # launch group are distinct; the last ntexts steps of a block -- the ones that get checked -- survive)
-    R = max(Geff, ntexts, 2)
+    # launch group are distinct; the last ncheck steps of a block -- the ones that get checked -- survive)
+    ncheck = max(1, min(ntexts, args.check_texts))      # the last steps of a block whose planes are checked
+    R = max(Geff, ncheck, 2)
     ring = not (world > 1 or K * cap * 8 <= (512 << 20)) and W * R < K
     slots = W * R if ring else K
 
@@ -362,7 +381,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     for rep in range(max(1, repeats)):
         fence()
         t0 = time.perf_counter()
-        host_issue.append(block(profiled if rep == repeats - 1 else plain))
+        host_issue.append(block(profiled))      # (worker 0's launch groups carry HIP events in every block)
         fence()
         blocks.append(time.perf_counter() - t0)
     k1_ms, k2_ms, pipe_ms, launches = matcher.profile_read()
@@ -434,7 +453,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
 
     # ---- parity: the planes of the last steps of the last block, every distinct text once -----------
     owner = {slot_of(k): k for k in range(K)}            # the last step that wrote each slot
-    last_k = [k for k in range(max(0, K - ntexts), K) if owner[slot_of(k)] == k]
+    last_k = [k for k in range(max(0, K - ncheck), K) if owner[slot_of(k)] == k]
     m_local = int(host_planes[slot_of(K - 1), 0, 0])
     m_total = m_local
     if world > 1:
@@ -547,7 +566,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "launches_timed": launches,
                 "stage_traffic": stage_traffic or None,
                 "note": "HIP events on the worker's own stream around the kernels of every %d-th launch group of worker 0 "
-                        "in the last timed block (1: all of them); with %d workers a kernel shares the GPU with the other workers' "
+                        "in every timed block (1: all of them); with %d workers a kernel shares the GPU with the other workers' "
                         "kernels.  traffic = the bulk kernel's counted HBM bytes for ONE batch (profiles/, collected "
                         "with --group 1) x batches_per_launch; stage_traffic: per batch" % (pe, W),
             },
@@ -598,7 +617,11 @@ def main():
     ap.add_argument("--workload", default="clamav2000", choices=["clamav2000", "clamav10000", "clamav15000", "sentiment"])
     ap.add_argument("--sub", default="clamav15000,sentiment",
                     help="workloads reported as sub-records of the line (N = 1 only); '' for none")
-    ap.add_argument("--texts", type=int, default=10, help="distinct 32 MiB texts the steps rotate over")
+    ap.add_argument("--texts", type=int, default=64,
+                    help="distinct 32 MiB texts the steps rotate over (64 = 2 GiB: no text is read twice within 256 MiB of traffic)")
+    ap.add_argument("--check-texts", type=int, default=16,
+                    help="the planes of the last this-many steps of the last block (distinct texts) are compared with the oracle")
+    ap.add_argument("--sub-texts", type=int, default=0, help="texts of the sub-record workloads (0: as --texts)")
     ap.add_argument("--plant", type=int, default=4096)
     ap.add_argument("--workers", type=int, default=0,
                     help="HIP streams the steps are dealt over (0: automatic = 3)")
@@ -664,7 +687,7 @@ def main():
             if not name or name == args.workload:
                 continue
             rec = run_workload(ctx, Workload(name, args.plant), args.steps, args.warmup, args.repeats,
-                               min(4, max(1, args.texts)), args.workers, not args.no_verify, False)
+                               max(1, args.sub_texts or args.texts), args.workers, not args.no_verify, False)
             if rec is not None:
                 subs[name] = rec
 

@@ -1043,39 +1043,70 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 	const uint32_t cap = std::min<uint32_t>((uint32_t)d->max_group, acm::sparse_max_group());
 	const acm_scan_batch *group[32];
 	uint32_t m = 0;
+	// Failure contract: "stops at the first batch that fails; the batches before it stay enqueued" --
+	// also inside a group: the members in front of the one that failed validation are launched (as a
+	// shorter group), and events taken from the pool go back to it on every error path.
 	auto flush = [&]() -> int {
 		int rc = ACM_OK;
-		if (m == 1) {
+		const uint32_t members = m;
+		m = 0;
+		if (members == 1) {
 			rc = enqueue_batch(d, group[0], true, nullptr);
-		} else if (m > 1) {
+		} else if (members > 1) {
 			acm::SieveJob jobs[32];
-			for (uint32_t i = 0; i < m && rc == ACM_OK; i++)
-				rc = enqueue_batch(d, group[i], true, &jobs[i]);
+			uint32_t good = 0;
+			int first_bad = ACM_OK;
+			for (; good < members; good++) {
+				first_bad = enqueue_batch(d, group[good], true, &jobs[good]);
+				if (first_bad != ACM_OK)
+					break;
+			}
 			hipStream_t gs = (hipStream_t)group[0]->stream;
 			hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-			if (rc == ACM_OK && group[0]->profile) {   // the group's kernels, timed like a single batch's
+			auto give_back = [&]() {
+				std::lock_guard<std::mutex> lock(d->profile_mutex);
+				for (auto &e : ev)
+					if (e) {
+						d->profile_pool.push_back((void *)e);
+						e = nullptr;
+					}
+			};
+			if (good > 0 && group[0]->profile) {   // the group's kernels, timed like a single batch's
 				std::lock_guard<std::mutex> lock(d->profile_mutex);
 				for (auto &e : ev) {
 					if (!d->profile_pool.empty()) {
 						e = (hipEvent_t)d->profile_pool.back();
 						d->profile_pool.pop_back();
 					} else if (hipEventCreate(&e) != hipSuccess) {
-						return acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventCreate failed");
+						e = nullptr;
+						rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventCreate failed");
+						break;
 					}
 				}
 			}
-			if (rc == ACM_OK && ev[0])
-				ACM_HIP_TRY(hipEventRecord(ev[0], gs));
-			if (rc == ACM_OK)
-				rc = acm::sparse_group_enqueue(d, jobs, m, gs, ev[1], ev[2]);
-			if (rc == ACM_OK && ev[0]) {
-				ACM_HIP_TRY(hipEventRecord(ev[3], gs));
-				std::lock_guard<std::mutex> lock(d->profile_mutex);
-				for (auto e : ev)
-					d->profile_events.push_back((void *)e);
+			if (rc != ACM_OK) {
+				give_back();
+				return rc;
 			}
+			if (good > 0) {
+				if (ev[0] && hipEventRecord(ev[0], gs) != hipSuccess)
+					rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventRecord failed");
+				if (rc == ACM_OK)
+					rc = acm::sparse_group_enqueue(d, jobs, good, gs, ev[1], ev[2]);
+				if (rc == ACM_OK && ev[0] && hipEventRecord(ev[3], gs) != hipSuccess)
+					rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventRecord failed");
+				if (rc == ACM_OK && ev[0]) {
+					std::lock_guard<std::mutex> lock(d->profile_mutex);
+					for (auto &e : ev) {
+						d->profile_events.push_back((void *)e);
+						e = nullptr;
+					}
+				}
+				give_back();   // (only what an error left behind)
+			}
+			if (rc == ACM_OK)
+				rc = first_bad;
 		}
-		m = 0;
 		return rc;
 	};
 	for (size_t i = 0; i < count; i++) {

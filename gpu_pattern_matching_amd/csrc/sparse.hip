@@ -117,6 +117,7 @@ struct SieveArgs {
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	uint32_t F, D;
+	uint32_t tail_walk;           // bytes side_walks() walks from the root at the end of the text: D - 1, or W + 4 with 6-byte filter keys
 	uint32_t run_ok[8];           // bit b: D copies of byte b are a trie path (a run of b can start a pattern)
 	// text
 	const uint4 *text16;
@@ -662,8 +663,12 @@ __device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, uint32_
 __device__ void side_walks(const SieveArgs &a)
 {
 	{
+		// exact wherever the state at the last byte is no deeper than the bytes walked.  A deeper state
+		// has a follower -- if its sample could be looked at: with 6-byte filter keys the sample of a path
+		// that starts less than W + 5 bytes before the end has its key cut off by the end of the text and
+		// is never flagged, so the walk covers W + 4 bytes then (tail_walk), not just D - 1
 		uint32_t st = 0;
-		for (uint32_t x = a.n > a.D - 1 ? a.n - (a.D - 1) : 0u; x < a.n; x++)
+		for (uint32_t x = a.n > a.tail_walk ? a.n - a.tail_walk : 0u; x < a.n; x++)
 			st = a.cold[((size_t)st << a.ls) | a.cls[a.text[x]]];
 		a.misc[0] = st;
 	}
@@ -937,7 +942,8 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 #pragma unroll
 								for (uint32_t k = 0; k < S; k++) {
 									const bool lok = k * W >= W - 1 || left;
-									const bool rok = k * W + 10 <= 16 || (k * W + 10 <= 20 ? right4 : right8);
+									const uint32_t reach = k * W + g.common.D;   // the candidate range ends here, counted from the lane's first byte
+									const bool rok = reach <= 16 || (reach <= 20 ? right4 : reach <= 24 ? right8 : false);
 									if (lok && rok)
 										fj &= ~(1u << k);
 								}
@@ -1299,11 +1305,10 @@ Geometry geometry_for(const acm_dfa *d, size_t n)
 
 namespace acm {
 
-size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
+namespace {
+size_t workspace_for_exactly(const acm_dfa *d, size_t n)
 {
-	if (!d->sparse_ok)
-		return 0;
-	const Geometry g = geometry_for(d, max_text);   // tile size and cap grow with the text, the tile count is bounded
+	const Geometry g = geometry_for(d, n);   // tile size and cap grow with the text, the tile count is bounded
 	size_t o = 0;
 	o += align_up((size_t)kMaxRows * kSummaryWords * 4, 256);
 	o += align_up((size_t)g.nrows * g.cap * 8, 256);
@@ -1313,6 +1318,20 @@ size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
 	o += align_up((size_t)kMaxTiles * 4, 256);
 	o += 256;
 	return o;
+}
+}  // namespace
+
+// Enough for every text of up to max_text bytes.  The need is not monotonic in n: where the tile
+// size doubles the number of rows halves while every row keeps its per-row terms, so the largest
+// text of each smaller tile size is looked at too (a scan lays the workspace out for its own n).
+size_t sparse_workspace_bytes(const acm_dfa *d, size_t max_text)
+{
+	if (!d->sparse_ok)
+		return 0;
+	size_t need = workspace_for_exactly(d, max_text);
+	for (size_t tile = kMinTile; tile * kMaxTiles < max_text; tile *= 2)
+		need = std::max(need, workspace_for_exactly(d, tile * kMaxTiles));
+	return need;
 }
 
 int sparse_prepare(const acm_dfa *)
@@ -1353,6 +1372,9 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.dev2ref = d->d_dev2ref;
 	a.F = d->first_final;
 	a.D = d->sv_prefix_len;
+	a.tail_walk = a.D - 1;
+	if (d->sv_gram_len == 6)
+		a.tail_walk = std::max(a.tail_walk, d->sv_stride + 4);
 	memcpy(a.run_ok, d->sv_run_ok, sizeof(a.run_ok));
 	a.n = (uint32_t)n;
 	a.n_pad = (uint32_t)((n + 15) & ~(size_t)15);

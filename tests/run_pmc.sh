@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() {   # name, counters...
   local name=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/${TAG}_$name -- python3 bench.py --workload $WL --sub "" --steps 40 --warmup 4 --repeats 2 --texts 4 --group 1 --no-extra --no-cpu-baseline --no-e2e --no-verify > gpurun_out/${TAG}_$name.json 2> gpurun_out/${TAG}_$name.err || { tail -5 gpurun_out/${TAG}_$name.err; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/${TAG}_$name -- python3 bench.py --workload $WL --sub "" --steps 40 --warmup 4 --repeats 2 --texts 12 --group 1 --no-extra --no-cpu-baseline --no-e2e --no-verify > gpurun_out/${TAG}_$name.json 2> gpurun_out/${TAG}_$name.err || { tail -5 gpurun_out/${TAG}_$name.err; exit 1; }
 }
 run FETCH_SIZE FETCH_SIZE
 run WRITE_SIZE WRITE_SIZE

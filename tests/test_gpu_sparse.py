@@ -414,6 +414,43 @@ def test_six_byte_filter_keys(gpu, shortest):
     m.close()
 
 
+def test_six_byte_keys_text_ends_inside_pattern(gpu):
+    """6-byte filter keys, stride 8 (shortest pattern 13, D = 10): a text that ends 10..12 bytes inside a
+    pattern, at every alignment of its start against the stride.  The one sample of such a path has its key
+    cut off by the end of the text, so no follower is made and the last state comes from the tail walk
+    (sparse.hip side_walks: W + 4 bytes, not D - 1).  The state must be the oracle's, and a second segment
+    that starts with the rest of the pattern must report it from that carried state."""
+    allp = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 1200)
+    pats = [p[:13 + (i % 40)] for i, p in enumerate(allp) if len(p) >= 13 + 40]
+    pats = list(dict.fromkeys(pats))[:600]
+    assert min(len(p) for p in pats) == 13
+    a, o = build(pats)
+    m = Matcher(a, 0, max_text=1 << 16)
+    assert m.set_mode("sparse") == "sparse"
+    rng = np.random.default_rng(1312)
+    checked = 0
+    for d in (9, 10, 11, 12, 13, 14):
+        for align in range(8):
+            P = pats[int(rng.integers(len(pats)))]
+            if len(P) <= d:
+                continue
+            n = 4096 + align + d                     # the pattern starts at 4096 + align
+            text = rng.integers(0, 256, size=n, dtype=np.uint8)
+            text[n - d:] = np.frombuffer(P[:d], dtype=np.uint8)
+            exp = o.scan(text)
+            got = m.scan(text)
+            assert_same(got, exp)
+            assert m.path_taken(text.size) == "sparse"
+            rest = np.concatenate([np.frombuffer(P[d:], dtype=np.uint8),
+                                   rng.integers(0, 256, size=512, dtype=np.uint8)])
+            exp2 = o.scan(rest, exp[2])
+            assert (len(P) - d - 1) in exp2[0].tolist()   # the straddling signature is reported
+            assert_same(m.scan(rest, got[2]), exp2)
+            checked += 1
+    assert checked >= 40
+    m.close()
+
+
 def test_real_binary_content(gpu):
     """Not synthetic: 48 MiB out of the middle of the largest ROCm library on the box (code, zero
     pages, tables, strings) x 2000 and 15000 signatures.  Whatever path the data makes the sparse
