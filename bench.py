@@ -506,7 +506,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         alg_batch = n_local + 8 * m_local
         # batches one launch of the bulk kernel processes (the timed groups' average: the last group
         # of a block may be short)
-        grouped = (timed_steps / max(launches, 1)) if (path == "sparse" and launches) else 1
+        grouped = (timed_steps * max(1, repeats) / max(launches, 1)) if (path == "sparse" and launches) else 1
         alg_bytes = int(alg_batch * grouped)
         kname = "k_sieve" if path == "sparse" else "k_spec_walk"
         L1 = max(launches, 1)

@@ -58,6 +58,8 @@ NATIVE_API = {
     "acm_automaton_num_patterns": (C.c_int, [_vp]),
     "acm_automaton_max_pattern_len": (C.c_int, [_vp]),
     "acm_automaton_byte_classes": (C.c_int, [_vp, _vp]),
+    "acm_compact_selftest": (C.c_int, [_vp, C.c_uint32, _u32p]),
+    "acm_compact_profile": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "acm_automaton_num_states": (C.c_int, [_vp]),
     "acm_automaton_reference_table_bytes": (C.c_size_t, [_vp]),
     "acm_automaton_export_reference_table": (C.c_int, [_vp, _i32p]),

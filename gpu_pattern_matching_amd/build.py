@@ -17,7 +17,7 @@ OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libacmatch.so")
 CLI = os.path.join(PKG, "acm_grep")          # native CLI (csrc/acm_grep.cpp), host code only
 
-SOURCES = ["automaton.cpp", "multi.cpp", "device_dfa.hip", "scan.hip", "sparse.hip", "post.hip", "runtime.hip", "compat.hip"]
+SOURCES = ["automaton.cpp", "compact_tables.cpp", "multi.cpp", "device_dfa.hip", "scan.hip", "lds_walk.hip", "sparse.hip", "post.hip", "runtime.hip", "compat.hip"]
 ARCH = "gfx950"
 
 

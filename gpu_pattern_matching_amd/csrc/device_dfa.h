@@ -53,6 +53,14 @@ struct acm_dfa {
 	mutable std::atomic<uint32_t> sparse_batches{0}, giveups_seen{0}, chain_hold{0};
 	mutable std::atomic<uint32_t> auto_window{16}, auto_next_hold{64};   // batches per look at the counter; chain batches after a bad look
 
+	// the automaton whole in LDS (lds_walk.hip, compact_tables.h): small alphabets, <= 16384 states
+	bool lds_ok = false;
+	uint8_t *d_lds_image = nullptr;      // what the walk kernel copies to LDS
+	int32_t *d_lds_out = nullptr;        // [compact id] reported pattern index
+	uint32_t *d_lds_cid2ref = nullptr;   // [compact id] reference id
+	uint32_t lds_image_bytes = 0, lds_off_rec = 0, lds_halo = 0, lds_rows = 0;
+	std::vector<uint16_t> lds_ref2code;  // host: state code of a reference id (init_state)
+
 	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies
 	int scan_mode = ACM_SCAN_MODE_AUTO;
 

@@ -38,6 +38,7 @@
 
 #include "acm_internal.h"
 #include "device_dfa.h"
+#include "lds_walk.h"
 #include "sieve_tables.h"
 #include "sparse.h"
 
@@ -338,6 +339,8 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		}
 		if (rc == ACM_OK)
 			rc = build_sieve(*a, d);
+		if (rc == ACM_OK)
+			rc = acm::lds_walk_prepare(a, d);
 		// match lists, for all-patterns reporting (post.hip, acm_expand_matches_async)
 		std::vector<uint32_t> lbegin(n, 0), llen(n, 0);
 		for (uint32_t r = 0; r < n; r++)
@@ -408,6 +411,7 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		free_small(d, d->d_sv_rec);
 		free_small(d, d->d_sv_edges);
 		hipFree(d->arena);
+		acm::lds_walk_release(d);
 		if (d->h_giveups)
 			hipHostFree(d->h_giveups);
 		(void)hipDeviceSynchronize();   // no exec is destroyed under a launch

@@ -55,6 +55,7 @@
 #include "acm_internal.h"
 #include "deep_walk.h"
 #include "device_dfa.h"
+#include "lds_walk.h"
 #include "sparse.h"
 
 namespace {
@@ -1008,7 +1009,14 @@ extern "C" int acm_scan_shard_async(const acm_dfa *d, const void *d_text, size_t
 
 namespace {
 bool pick_sparse(const acm_dfa *d, size_t n);
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer);
+// what enqueue_batch leaves to the caller when it defers the launches of a batch that joins a group
+struct Deferred {
+	acm::SieveJob sieve;
+	acm::LdsJob lds;
+};
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, Deferred *defer);
+// the chain pipeline's LDS-resident form takes launch groups too (lds_walk.hip)
+bool lds_path(const acm_dfa *d, bool sparse, size_t n) { return !sparse && d->lds_ok && d->use_halo && n > 0; }
 
 // consecutive sparse batches of one size on one stream, each with its own workspace and planes,
 // that wait for nothing and are not timed: one group for the sparse kernels
@@ -1040,9 +1048,10 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 		}
 		return ACM_OK;
 	}
-	const uint32_t cap = std::min<uint32_t>((uint32_t)d->max_group, acm::sparse_max_group());
+	const uint32_t cap = std::min<uint32_t>((uint32_t)d->max_group, std::min(acm::sparse_max_group(), acm::lds_walk_max_group()));
 	const acm_scan_batch *group[32];
 	uint32_t m = 0;
+	bool group_sparse = true;   // the pipeline of the group being collected
 	// Failure contract: "stops at the first batch that fails; the batches before it stay enqueued" --
 	// also inside a group: the members in front of the one that failed validation are launched (as a
 	// shorter group), and events taken from the pool go back to it on every error path.
@@ -1051,13 +1060,13 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 		const uint32_t members = m;
 		m = 0;
 		if (members == 1) {
-			rc = enqueue_batch(d, group[0], true, nullptr);
+			rc = enqueue_batch(d, group[0], group_sparse, nullptr);
 		} else if (members > 1) {
-			acm::SieveJob jobs[32];
+			Deferred jobs[32];
 			uint32_t good = 0;
 			int first_bad = ACM_OK;
 			for (; good < members; good++) {
-				first_bad = enqueue_batch(d, group[good], true, &jobs[good]);
+				first_bad = enqueue_batch(d, group[good], group_sparse, &jobs[good]);
 				if (first_bad != ACM_OK)
 					break;
 			}
@@ -1091,8 +1100,19 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 			if (good > 0) {
 				if (ev[0] && hipEventRecord(ev[0], gs) != hipSuccess)
 					rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventRecord failed");
-				if (rc == ACM_OK)
-					rc = acm::sparse_group_enqueue(d, jobs, good, gs, ev[1], ev[2]);
+				if (rc == ACM_OK && group_sparse) {
+					acm::SieveJob sj[32];
+					for (uint32_t i = 0; i < good; i++)
+						sj[i] = jobs[i].sieve;
+					rc = acm::sparse_group_enqueue(d, sj, good, gs, ev[1], ev[2]);
+				} else if (rc == ACM_OK) {
+					acm::LdsJob lj[32];
+					for (uint32_t i = 0; i < good; i++)
+						lj[i] = jobs[i].lds;
+					rc = acm::lds_walk_enqueue(d, lj, good, gs, ev[1], nullptr);
+					if (rc == ACM_OK && ev[2] && hipEventRecord(ev[2], gs) != hipSuccess)   // (the walk is the first stage, there is no second)
+						rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventRecord failed");
+				}
 				if (rc == ACM_OK && ev[0] && hipEventRecord(ev[3], gs) != hipSuccess)
 					rc = acm::fail(ACM_ERR_HIP, "acm_scan_batches_async: hipEventRecord failed");
 				if (rc == ACM_OK && ev[0]) {
@@ -1112,12 +1132,13 @@ extern "C" int acm_scan_batches_async(const acm_dfa *d, const acm_scan_batch *ba
 	for (size_t i = 0; i < count; i++) {
 		const acm_scan_batch &b = batches[i];
 		const bool sparse = pick_sparse(d, b.n);   // (counts the batch: once per batch)
-		if (sparse && groupable(d, b)) {
-			if (m && (m >= cap || !joins(group, m, b))) {
+		if ((sparse || lds_path(d, sparse, b.n)) && groupable(d, b)) {
+			if (m && (m >= cap || sparse != group_sparse || !joins(group, m, b))) {
 				const int rc = flush();
 				if (rc != ACM_OK)
 					return rc;
 			}
+			group_sparse = sparse;
 			group[m++] = &b;
 			continue;
 		}
@@ -1144,7 +1165,7 @@ int scan_prepare(const acm_dfa *)
 }  // namespace acm
 
 namespace {
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer = nullptr);
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, Deferred *defer = nullptr);
 
 // what a cached graph was captured for: every input of enqueue_batch except the stream
 acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b, bool sparse)
@@ -1283,9 +1304,9 @@ extern "C" int acm_scan_set_graphs(acm_dfa *d, int enable)
 }
 
 namespace {
-// defer: (sparse only) check and lay out as always, but leave the launches to the caller, who
-// enqueues a group of such batches with one set of kernels (acm_scan_batches_async)
-int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, acm::SieveJob *defer)
+// defer: (sparse pipeline, LDS walk) check and lay out as always, but leave the launches to the caller,
+// who enqueues a group of such batches with one set of kernels (acm_scan_batches_async)
+int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, Deferred *defer)
 {
 	const void *d_text = batch->d_text;
 	const size_t n = batch->n, halo = batch->halo;
@@ -1420,10 +1441,37 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, ac
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
 	if (sparse && defer) {
-		defer->batch = batch;
-		defer->init_dev = a.init_state;
-		defer->sparse_ws = ws + l.sparse;
-		defer->path_marker = a.misc + 2;
+		defer->sieve.batch = batch;
+		defer->sieve.init_dev = a.init_state;
+		defer->sieve.sparse_ws = ws + l.sparse;
+		defer->sieve.path_marker = a.misc + 2;
+		return ACM_OK;
+	}
+	if (lds_path(d, sparse, n)) {   // the automaton fits the LDS whole: walk + scatter of lds_walk.hip
+		acm::LdsJob job;
+		job.batch = batch;
+		job.stage = (uint32_t *)(ws + l.stage1);
+		job.cnt = (uint8_t *)(ws + l.cnt);
+		job.tile_total = (uint32_t *)(ws + l.off);
+		job.misc = a.misc;
+		size_t stage_words, cnt_bytes, tile_words;
+		acm::lds_walk_needs(d, n, &stage_words, &cnt_bytes, &tile_words);
+		if (stage_words * 4 > l.stage2 - l.stage1 || cnt_bytes > l.off - l.cnt || tile_words * 4 > l.wave_cnt1 - l.off)
+			return acm::fail(ACM_ERR_ARG, "acm_scan_async: workspace layout too small for the LDS walk");
+		if (defer) {
+			defer->lds = job;
+			return ACM_OK;
+		}
+		rc = acm::lds_walk_enqueue(d, &job, 1, s, profile ? ev[1] : nullptr, (hipEvent_t)batch->record_after_walk);
+		if (rc != ACM_OK)
+			return rc;
+		if (profile) {
+			ACM_HIP_TRY(hipEventRecord(ev[2], s));
+			ACM_HIP_TRY(hipEventRecord(ev[3], s));
+			std::lock_guard<std::mutex> lock(d->profile_mutex);
+			for (auto e : ev)
+				d->profile_events.push_back((void *)e);
+		}
 		return ACM_OK;
 	}
 	if (sparse) {   // three kernels of its own; it always produces the planes

@@ -86,6 +86,19 @@ int acm_automaton_max_pattern_len(const acm_automaton *);
  * (no compression).  class_of, if not NULL, gets the 256-entry byte -> class
  * map.  The chain pipeline's planes have one cell per class. */
 int acm_automaton_byte_classes(const acm_automaton *, uint8_t *class_of);
+/* The LDS-resident form of a small automaton (full rows for the shallow states, a 4-byte record
+ * for every other: csrc/compact_tables.h), built on the host and checked transition by transition
+ * against the dense DFA -- no device needed.  lds_bytes: what the image may take (0: a CU's 160 KiB
+ * less a margin).  Returns 1 if the set qualifies and every (state, byte) transition agrees, 0 if it
+ * does not qualify (too many states or byte classes, or the rows that must be full do not fit),
+ * negative on error.  stats, if not NULL, gets 9 words: states, classes, rows, side entries, image
+ * bytes, rows beyond the mandatory ones, simple records, side entries ending in a row, side entries
+ * deferring to the fail state. */
+int acm_compact_selftest(const acm_automaton *, uint32_t lds_bytes, uint32_t *stats);
+/* tuning aid, host only: walks text through the LDS form from the root; counts[5] = steps, steps
+ * decided by the record or a row alone, by one side entry, by more than one hop, final states entered.
+ * Returns 1, or 0 if the set does not qualify. */
+int acm_compact_profile(const acm_automaton *, const unsigned char *text, size_t n, uint64_t *counts);
 /* states as acsm_get_states reports them after acsm_gen_state_table */
 int acm_automaton_num_states(const acm_automaton *);
 /* bytes of the reference's serialised table: states * 2 * 256 * 4 */

@@ -15,9 +15,10 @@ import glob
 import json
 import sys
 
-STREAMING = ("k_sieve<", "k_sieveI", "k_spec_walk", "k_halo_walk")     # the kernels that read the text, 16 B per lane
+STREAMING = ("k_sieve<", "k_sieveI", "k_spec_walk", "k_halo_walk", "k_lds_walk")     # the kernels that read the text, 16 B per lane
 SQ = ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM",
-      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")
+      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY",
+      "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_WAIT_INST_ANY")
 
 
 def collect(pattern, names):
@@ -50,7 +51,8 @@ def main(prefix, out):
     # short names as keys too, so that bench.py finds "k_sieve" / "k_spec_walk"
     short = {}
     for k, d in res.items():
-        for name in ("k_sieve_check", "k_sieve_emit", "k_sieve", "k_spec_walk", "k_halo_walk", "k_probe", "k_resolve", "k_scatter_all"):
+        for name in ("k_sieve_check", "k_sieve_emit", "k_sieve", "k_spec_walk", "k_halo_walk", "k_probe", "k_resolve", "k_scatter_all",
+                     "k_lds_walk", "k_lds_scatter"):
             if name in k and name not in short and (name != "k_sieve" or ("k_sieve_" not in k)):
                 short[name] = d
     res.update(short)
