@@ -233,9 +233,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     G = matcher.lib.acm_scan_set_max_group(matcher.dfa, G)
     wss = [[torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(G)] for _ in range(W)]
     pe = max(1, args.profile_every)
-    # launch groups exist for the sparse pipeline only: a workload that runs the chain pipeline is dealt to
-    # the workers step by step (else a 20-step block would put 16 consecutive steps on one stream)
-    groups_apply = matcher.sparse_eligible() and args.mode != "chain"
+    # launch groups exist for the sparse pipeline and for the chain pipeline's LDS-resident walk; a workload on
+    # the cold-plane chain kernels is dealt to the workers step by step (else a 20-step block would put 16
+    # consecutive steps on one stream)
+    groups_apply = matcher.group_capable()
     Geff = G if (args.issue != "main" and groups_apply) else 1
 
     # The steps are dealt to the workers a launch group at a time: steps 0 .. Geff-1 to worker 0, the next
@@ -423,6 +424,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
             torch.cuda.synchronize()
         g_k1, g_k2, g_pipe, g_n = matcher.profile_read()
     path = matcher.path_taken(n_local, streams[0].cuda_stream, workspace=(wss[0][0].data_ptr(), ws_bytes))
+    matcher_lds = matcher.lds_resident()
 
     red = dev if ctx["backend"] == "nccl" else torch.device("cpu")
     if world > 1:
@@ -506,21 +508,25 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         alg_batch = n_local + 8 * m_local
         # batches one launch of the bulk kernel processes (the timed groups' average: the last group
         # of a block may be short)
-        grouped = (timed_steps * max(1, repeats) / max(launches, 1)) if (path == "sparse" and launches) else 1
+        grouped = (timed_steps * max(1, repeats) / max(launches, 1)) if (groups_apply and launches) else 1
         alg_bytes = int(alg_batch * grouped)
-        kname = "k_sieve" if path == "sparse" else "k_spec_walk"
+        kname = "k_sieve" if path == "sparse" else ("k_lds_walk" if matcher_lds else "k_spec_walk")
         L1 = max(launches, 1)
         k_s = k1_ms / 1e3 / L1
         achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
         value = total_bytes * K / elapsed / 1e9
         traffic, stage_traffic = None, {}
-        tfile = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % wl.name)
+        tfile = os.path.join(ROOT, "profiles", "r3_traffic_%s.json" % wl.name)
+        if not os.path.exists(tfile):
+            tfile = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % wl.name)
         if os.path.exists(tfile):
             for name, rec in json.load(open(tfile)).items():
                 if name.startswith("k_"):     # (the short names; the file also has the full ones and the copies)
                     stage_traffic[name] = round(rec["hbm_bytes_per_launch"], 1)
             if kname == "k_spec_walk" and "k_halo_walk" in stage_traffic and "k_spec_walk" not in stage_traffic:
                 kname = "k_halo_walk"     # (halo mode with the text loaded up front: its own kernel)
+            if kname == "k_lds_walk" and "k_lds_walk" not in stage_traffic:
+                stage_traffic = {}        # (counters of the kernels this workload no longer runs)
             traffic = stage_traffic.get(kname)
             if traffic is not None:
                 traffic = round(traffic * grouped, 1)     # (the counters were collected with one batch per launch)
@@ -538,10 +544,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "text_residency": residency,
                 "pipeline": path,
                 "workers": W,
-                "batches_in_flight": W * (G if (path == "sparse" and args.issue != "main") else 1),
+                "batches_in_flight": W * (G if (groups_apply and args.issue != "main") else 1),
                 "host_threads": W if pool is not None else 1,
                 "issue": args.issue,
-                "batches_per_launch_group": G if (path == "sparse" and args.issue != "main") else 1,
+                "batches_per_launch_group": G if (groups_apply and args.issue != "main") else 1,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
             },
@@ -581,7 +587,7 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "frac": round(alg_batch / sk / 1e9 / HBM_PEAK_GBS, 5),
                 "launches": s_n,
             }
-        if g_n and path == "sparse":
+        if g_n and groups_apply:
             gk = g_k1 / 1e3 / g_n
             out["roofline_one_group_in_flight"] = {
                 "batches_per_launch": Geff,

@@ -86,6 +86,8 @@ NATIVE_API = {
     "acm_scan_set_mode": (C.c_int, [_vp, C.c_int]),
     "acm_scan_set_graphs": (C.c_int, [_vp, C.c_int]),
     "acm_scan_sparse_eligible": (C.c_int, [_vp]),
+    "acm_scan_lds_resident": (C.c_int, [_vp]),
+    "acm_scan_group_capable": (C.c_int, [_vp]),
     "acm_scan_path_taken": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "acm_scan_profile_enable": (C.c_int, [_vp, C.c_int]),
     "acm_scan_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -203,6 +203,14 @@ class Matcher:
     def sparse_eligible(self):
         return bool(self.lib.acm_scan_sparse_eligible(self.dfa))
 
+    def lds_resident(self):
+        """the chain pipeline walks this set with the whole automaton in LDS (lds_walk.hip)"""
+        return bool(self.lib.acm_scan_lds_resident(self.dfa))
+
+    def group_capable(self):
+        """consecutive batches of one size share their launches in the current mode (acm_scan_batches_async)"""
+        return bool(self.lib.acm_scan_group_capable(self.dfa))
+
     def path_taken(self, n, stream=None, workspace=None):
         """Which pipeline produced the planes of the last n-byte scan (synchronises)."""
         st = stream if stream is not None else self.stream

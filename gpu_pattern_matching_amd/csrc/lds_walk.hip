@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kWalkBlock = 1024;               // 16 waves: the whole CU (the image takes all of its LDS)
 constexpr int kWalkWaves = kWalkBlock / 64;
-constexpr int kScatterBlock = 256;
+constexpr int kScatterBlock = 1024;             // chains per scatter workgroup (every workgroup adds up the tile totals in front of it: fewer, larger ones)
 constexpr uint32_t kChainBytes = 64, kLogChain = 6;
 constexpr uint32_t kMaxHaloGroups = 2;         // hb <= 32: patterns of up to 33 bytes
 constexpr uint32_t kGroups = kChainBytes / 16 + kMaxHaloGroups;   // 16-byte groups a lane holds per chain
@@ -605,12 +605,24 @@ __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 		const uint32_t *list = b.stage + (size_t)tile * (C * kChainBytes * 64) + slot * (kChainBytes * 64) + lane;
 		const int32_t *outp = b.report_state ? (const int32_t *)g.cid2ref : g.out;
 		const uint32_t base = j << kLogChain;
-		for (uint32_t k = 0; k < c; k++, d++) {
-			const uint32_t rec = list[k * 64];
-			if (d + 2 < b.plane_capacity) {
-				b.pat_plane[1 + d] = outp[(rec & 0x7FFEu) >> 1];
-				b.off_plane[1 + d] = (int32_t)(base + (rec >> 16)) + b.off_shift;
-			}
+		// four records a round: their loads, then the four pattern lookups, then the stores -- a wave takes as
+		// many rounds as its busiest lane has records, so a round should not be a chain of dependent loads
+		for (uint32_t k = 0; k < c; k += 4) {
+			uint32_t rec[4];
+			int32_t pat[4];
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				rec[i] = list[min(k + i, c - 1) * 64];
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				pat[i] = outp[(rec[i] & 0x7FFEu) >> 1];
+#pragma unroll
+			for (uint32_t i = 0; i < 4; i++)
+				if (k + i < c && d + i + 2 < b.plane_capacity) {
+					b.pat_plane[1 + d + i] = pat[i];
+					b.off_plane[1 + d + i] = (int32_t)(base + (rec[i] >> 16)) + b.off_shift;
+				}
+			d += 4;
 		}
 	}
 	if (blk == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)

@@ -964,6 +964,14 @@ extern "C" int acm_scan_set_mode(acm_dfa *d, int mode)
 }
 
 extern "C" int acm_scan_sparse_eligible(const acm_dfa *d) { return d && d->sparse_ok ? 1 : 0; }
+extern "C" int acm_scan_lds_resident(const acm_dfa *d) { return d && d->lds_ok && d->use_halo ? 1 : 0; }
+extern "C" int acm_scan_group_capable(const acm_dfa *d)
+{
+	if (!d || d->use_graphs || d->max_group <= 1)
+		return 0;
+	const bool sparse = d->sparse_ok && d->scan_mode != ACM_SCAN_MODE_CHAIN;
+	return (sparse || (d->lds_ok && d->use_halo)) ? 1 : 0;
+}
 
 extern "C" int acm_scan_path_taken(const acm_dfa *d, const void *d_workspace, size_t n, void *stream)
 {

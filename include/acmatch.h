@@ -289,6 +289,13 @@ enum { ACM_SCAN_MODE_AUTO = 0, ACM_SCAN_MODE_CHAIN = 1, ACM_SCAN_MODE_SPARSE = 2
 int acm_scan_set_mode(acm_dfa *, int mode);
 /* 1 when the pattern set qualifies for the sparse pipeline */
 int acm_scan_sparse_eligible(const acm_dfa *);
+/* 1 when the chain pipeline walks this set with the whole automaton in LDS (csrc/lds_walk.hip: small
+ * alphabet, at most 16384 states, patterns of at most 33 bytes); 0: hot rows in LDS + cold plane in HBM */
+int acm_scan_lds_resident(const acm_dfa *);
+/* 1 when consecutive batches of one size handed to acm_scan_batches_async can share their kernel
+ * launches in the current mode: the sparse pipeline's batches, and the chain pipeline's when the
+ * automaton is LDS-resident */
+int acm_scan_group_capable(const acm_dfa *);
 /* after a scan of n bytes with this workspace has been enqueued on stream:
  * waits for the stream and says which pipeline produced the planes --
  * ACM_SCAN_MODE_CHAIN or ACM_SCAN_MODE_SPARSE (0xDEAD: the sparse kernels found
