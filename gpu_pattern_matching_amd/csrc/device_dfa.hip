@@ -363,7 +363,7 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		return ACM_ERR_HIP;
 	}
 	if (d->sparse_ok && hipHostMalloc((void **)&d->h_giveups, 64, hipHostMallocMapped) == hipSuccess) {
-		*d->h_giveups = 0;
+		memset(d->h_giveups, 0, 64);
 		if (hipHostGetDevicePointer((void **)&d->d_giveups, d->h_giveups, 0) != hipSuccess)
 			d->d_giveups = nullptr;
 	}

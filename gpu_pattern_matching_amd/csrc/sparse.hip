@@ -94,10 +94,18 @@ constexpr uint32_t kSummaryWords = 8;      // per tile: extent + 1, hits, first,
 constexpr uint32_t kGaveUp = 0xFFFFFFFFu;  // hit count of a tile whose list was full (cannot happen: geometry_for)
 constexpr uint32_t kMarkerFailed = 0xDEADu; // path marker of a scan that did not produce planes
 constexpr uint32_t kDenseDivisor = 128;    // more than a record per this many bytes: a dense batch
+constexpr uint32_t kHeavyDivisor = 512;    // more than a flagged sample per this many bytes: the next launches get helper waves (k_sieve_check)
 constexpr uint32_t kBusyDivisor = 256;     // ... or a flagged sample per this many: the check kernel's time, not the bulk kernel's, is the batch's
 constexpr int kEmitBlock = 1024;
-constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // checker waves + the carried-state walker
-constexpr uint32_t kRowsPerThread = (kMaxRows + kEmitBlock - 1) / kEmitBlock;
+constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // static rows: the carried-state walker + a block of eight tiles each
+// A block whose tiles hold more flagged samples than this (real binaries: the 3-grams of code and tables
+// cluster) is cut into SUB-ROWS of at most this many samples, in position order; the block's own wave
+// takes the first, the others are numbered through the whole batch in block order and dealt to the
+// helper waves by that number.  No list, no counter, nobody waits: every helper works the numbering
+// out for itself from the tiles' sample counts, as the emit kernel does from the rows' summaries.  To
+// the emit kernel a sub-row is a row like any other.
+constexpr uint32_t kSubRow = 256;
+constexpr uint32_t kHelperWaves = 512;     // waves per batch that do nothing but sub-rows (they leave at once when there are none)
 
 struct SieveArgs {
 	// tables
@@ -126,7 +134,8 @@ struct SieveArgs {
 	uint32_t init_state, drop_before;
 	int32_t off_shift;
 	// geometry
-	uint32_t tile_bytes, ntiles, cap, nrows;   // nrows: checker waves + 1
+	uint32_t tile_bytes, ntiles, cap, nrows;   // nrows: static rows = blocks of eight tiles + 1 (the walker's)
+	uint32_t max_extra, sub_k;                 // sub-rows a text can have at most; list room a sub-row needs on top of its span
 	// workspace
 	uint2 *shead, *lhead;   // [ntiles][kSampleHead], [nrows][kHitHead]: the first entries of the lists below
 	uint2 *samples;      // [ntiles][scap] {position, 3-gram} of the samples the filter flagged, ascending
@@ -198,9 +207,14 @@ __device__ __forceinline__ SieveArgs batch_view(const SieveGroup &g, uint32_t bi
 // in the list proper.
 constexpr uint32_t kSampleHead = 32;   // a check wave reads a tile's samples one per lane
 constexpr uint32_t kHitHead = 8;       // the emit kernel reads a row's first hits 64 bytes per thread: rows side by side
-__device__ __forceinline__ uint2 *hit_slot(const SieveArgs &a, uint32_t row, uint32_t idx)
+// where a row keeps what: its summary and the dense head of its hit list under its slot, the rest of
+// the list from entry `lbase` of the lists on (a block's sub-rows share the block's region)
+struct RowRef {
+	uint32_t slot, lbase;
+};
+__device__ __forceinline__ uint2 *hit_slot(const SieveArgs &a, RowRef row, uint32_t idx)
 {
-	return idx < kHitHead ? a.lhead + (size_t)row * kHitHead + idx : a.lists + (size_t)row * a.cap + idx;
+	return idx < kHitHead ? a.lhead + (size_t)row.slot * kHitHead + idx : a.lists + (size_t)row.lbase + idx;
 }
 __device__ __forceinline__ uint2 *sample_slot(const SieveArgs &a, uint32_t tile, uint32_t idx)
 {
@@ -319,7 +333,7 @@ struct Follow {
 };
 
 __device__ __forceinline__ void final_node(const SieveArgs &a, LaneHits &h, uint32_t x, uint32_t value, bool take,
-    int mode, uint32_t floor, uint32_t row, uint32_t at)
+    int mode, uint32_t floor, RowRef row, uint32_t at)
 {
 	if (mode == kKeep) {
 		note_hit(h, x, value, take);
@@ -334,7 +348,7 @@ __device__ __forceinline__ void final_node(const SieveArgs &a, LaneHits &h, uint
 }
 
 __device__ __forceinline__ Follow follow(const SieveArgs &a, LaneHits &h, uint32_t node, uint32_t run, uint32_t x, int mode,
-    uint32_t floor, uint32_t row, uint32_t at)
+    uint32_t floor, RowRef row, uint32_t at)
 {
 	Follow f;
 	if (node >= a.F)   // a pattern of exactly D bytes, or one that ends a longer suffix
@@ -542,18 +556,20 @@ struct Row {
 	uint32_t akey, anode;
 	uint32_t gave_up;
 	uint32_t samples;    // flagged samples the row looked at (for AUTO mode: the emit kernel adds them up)
+	uint32_t room;       // entries its list has room for
 };
 
-__device__ __forceinline__ void write_summary(const SieveArgs &a, const Row &t, uint32_t row)
+// word 7 of a static row: sub-rows of its block beyond its own; of a sub-row: where its list starts
+__device__ __forceinline__ void write_summary(const SieveArgs &a, const Row &t, uint32_t slot, uint32_t word7)
 {
-	uint32_t *s = a.summary + (size_t)row * kSummaryWords;
+	uint32_t *s = a.summary + (size_t)slot * kSummaryWords;
 	*(uint4 *)s = make_uint4(t.carry, t.gave_up ? kGaveUp : t.count, t.first, t.last);
-	*(uint4 *)(s + 4) = make_uint4(t.akey, t.anode, t.samples, 0);
+	*(uint4 *)(s + 4) = make_uint4(t.akey, t.anode, t.samples, word7);
 }
 
 // Stage 2, one follower per lane (ascending starts): follow, shadow across the lanes, append the
 // surviving hits to the row's list.
-__device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, uint32_t row, uint32_t s, uint32_t node,
+__device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, RowRef row, uint32_t s, uint32_t node,
     uint32_t run, bool act, uint32_t lane, uint32_t &dbg_levels)
 {
 	LaneHits h;
@@ -569,7 +585,7 @@ __device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, uint32_
 			h.levels = 0;
 		}
 		if (act && (mode == kKeep || big)) {
-			const Follow f = follow(a, h, node, run, s + a.D - 1, mode, M, 0, 0);
+			const Follow f = follow(a, h, node, run, s + a.D - 1, mode, M, RowRef{ 0, 0 }, 0);
 			E = f.extent1;
 			if (f.at_end) {
 				akey = s + 2;
@@ -674,6 +690,7 @@ __device__ void side_walks(const SieveArgs &a)
 	}
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.samples = 0;
+	t.room = a.cap;
 	uint32_t state = a.init_state, x = 0;   // x: next byte to consume
 	uint32_t run = 0;                        // known unary, non-final path ahead of 'state'
 	while (state != 0) {
@@ -706,7 +723,7 @@ __device__ void side_walks(const SieveArgs &a)
 				t.gave_up = 1;
 				break;
 			}
-			*hit_slot(a, 0, t.count) = make_uint2(x, (uint32_t)a.out[state]);
+			*hit_slot(a, RowRef{ 0, 0 }, t.count) = make_uint2(x, (uint32_t)a.out[state]);
 			if (t.count == 0)
 				t.first = x;
 			t.last = x;
@@ -714,7 +731,7 @@ __device__ void side_walks(const SieveArgs &a)
 		}
 		x++;
 	}
-	write_summary(a, t, 0);
+	write_summary(a, t, 0, 0);
 }
 
 // Text loads the compiler does not know of, with the waits placed by hand (a wait names the
@@ -987,67 +1004,74 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 }
 
 // ------------------------------------------------------------------- K2 ---
-// The checks.  A wave takes the sample lists of kTilesPerChecker consecutive tiles, one
-// behind the other, 64 samples a round (stage 1); what stage 1 finds to be trie paths it
-// follows 64 at a time (stage 2).  A few hundred waves, each a chain of dependent loads:
-// latency-bound, light on everything else -- it runs beside the next batch's bulk pass.
-// The last workgroup walks the carried state and the tail instead.
-template <int W>
-__global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
+// The checks.  A block of kTilesPerChecker consecutive tiles is a ROW of the emit kernel's input: its
+// flagged samples, one list behind the other, are looked at 64 a round (stage 1); what stage 1 finds
+// to be trie paths is followed 64 at a time (stage 2).  A few hundred waves, each a chain of dependent
+// loads: latency-bound, light on everything else -- it runs beside the next batch's bulk pass.
+// On real binaries the samples cluster (a block can hold thousands where most hold a dozen), so a
+// block with more than kSubRow of them is cut into sub-rows of kSubRow samples: the block's own wave
+// announces them on the batch's work list and takes the first; every wave that has done its own work
+// -- and kHelperWaves that have none of their own -- takes sub-rows off the list until it is empty.
+// Nobody waits for anybody: a block's wave empties the list itself if no one else does.  One more
+// workgroup per batch walks the carried state and the tail.
+struct BlockCounts {
+	uint32_t cum[kTilesPerChecker + 1];   // samples in front of each of the block's tiles (wave-uniform)
+	uint32_t mycount;                     // of the tile this lane looks at in the speculative round
+	uint2 spec;                           // that tile's sample for this lane
+};
+constexpr uint32_t kSpecLanes = 64 / kTilesPerChecker;   // lanes (= samples) per tile in the speculative round
+static_assert(64 % kTilesPerChecker == 0 && kSampleHead >= kSpecLanes, "the speculative first round deals the lanes evenly");
+
+// the counts of a block's tiles and, in the same load level, the first samples of each: when no tile has
+// more than its share of the lanes (nearly always) that is the first and only stage-1 round
+__device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, uint32_t lane, BlockCounts &bc)
 {
-	__shared__ uint32_t q2[3][kQ2Cap];
-	const uint32_t lane = threadIdx.x;
-	// The workgroups of a launch are dealt over the group's batches, nrows each rounded up to a
-	// multiple of 8: workgroup ids go round the 8 XCDs, and row r of EVERY batch should land on the
-	// XCD whose bulk-kernel workgroup r read the row's tiles a moment ago -- its L2 still has them.
-	const uint32_t per = (g.common.nrows + 7u) & ~7u, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
-	if (blk >= g.common.nrows)
-		return;
-	const SieveArgs a = batch_view(g, bi);
-	if (blk == g.common.nrows - 1) {
-		if (threadIdx.x == 0)
-			side_walks(a);
-		return;
-	}
 	const uint32_t tile0 = blk * kTilesPerChecker;
-	unsigned long long *stamp = a.stamps ? a.stamps + (size_t)(blk + 8192) * 8 : nullptr;
+	const uint32_t my_tile = tile0 + lane / kSpecLanes, my_idx = lane % kSpecLanes;
+	const bool tile_ok = my_tile < a.ntiles;
+	const uint32_t tile_c = tile_ok ? my_tile : tile0;
+	bc.mycount = tile_ok ? a.scount[tile_c] : 0u;
+	bc.spec = a.shead[(size_t)tile_c * kSampleHead + my_idx];
+	bc.cum[0] = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < kTilesPerChecker; k++)
+		bc.cum[k + 1] = bc.cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)bc.mycount, (int)(k * kSpecLanes));
+}
+
+// Sub-row j of block blk: its samples [j * kSubRow, (j + 1) * kSubRow) through both stages, its summary
+// under `slot`.  word7: what a static row's summary says about its block's sub-rows.
+template <int W>
+__device__ __forceinline__ void check_subrow(const SieveArgs &a, uint32_t (*q2)[kQ2Cap], uint32_t lane, uint32_t blk, uint32_t j,
+    uint32_t slot, uint32_t word7, const BlockCounts &bc, unsigned long long *stamp)
+{
+	const uint32_t tile0 = blk * kTilesPerChecker;
 	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
-	if (stamp && lane == 0)
-		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	Row t;
-	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.samples = 0;
-	const uint32_t row = blk + 1;   // row 0 is the carried-state walker's
+	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
+	const uint32_t ns = bc.cum[kTilesPerChecker];
+	const uint32_t lo = j * kSubRow, hi = min(ns, lo + kSubRow);
+	t.samples = j == 0 ? ns : 0u;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
+	// the block's list region; a sub-row's part of it starts where its first sample lies, plus the room
+	// the sub-rows in front need beyond their spans (set below, once that sample is known)
+	RowRef row;
+	row.slot = slot;
+	row.lbase = (blk + 1) * a.cap;
+	t.room = a.cap;   // (a sub-row behind the first: what is left of the block's region, set with lbase below)
 	FollowerQueue fq;
 	fq.start = q2[0];
 	fq.node = q2[1];
 	fq.run = q2[2];
 	fq.count = 0;
-	// the lists of this wave's tiles, one behind the other.  With the counts, in the same load
-	// level, the first samples of each tile, an equal share of the wave's lanes per tile: when no
-	// tile has more (nearly always) that is the first and only stage-1 round, lanes in position order.
-	constexpr uint32_t kSpecLanes = 64 / kTilesPerChecker;   // lanes (= samples) per tile in the speculative round
-	static_assert(64 % kTilesPerChecker == 0 && kSampleHead >= kSpecLanes, "the speculative first round deals the lanes evenly");
-	const uint32_t my_tile = tile0 + lane / kSpecLanes, my_idx = lane % kSpecLanes;
-	const bool tile_ok = my_tile < a.ntiles;
-	const uint32_t tile_c = tile_ok ? my_tile : tile0;
-	const uint32_t mycount = tile_ok ? a.scount[tile_c] : 0u;
-	const uint2 spec = a.shead[(size_t)tile_c * kSampleHead + my_idx];
-	uint32_t cum[kTilesPerChecker + 1];
-	cum[0] = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < kTilesPerChecker; k++)
-		cum[k + 1] = cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)mycount, (int)(k * kSpecLanes));
-	const uint32_t nsamples = cum[kTilesPerChecker];
-	t.samples = nsamples;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
-	uint32_t r0 = 0;
-	if (nsamples && !__ballot(mycount > kSpecLanes)) {
+	uint32_t r0 = lo;
+	bool placed = j == 0;
+	if (j == 0 && ns && !__ballot(bc.mycount > kSpecLanes)) {
 		dbg_rounds++;
-		dbg_cands += nsamples;
-		r0 = nsamples;
-		stage1_round<W>(a, fq, spec.x, spec.y, my_idx < mycount, lane);
+		dbg_cands += ns;
+		r0 = ns;
+		stage1_round<W>(a, fq, bc.spec.x, bc.spec.y, lane % kSpecLanes < bc.mycount, lane);
 	}
 	for (;;) {
-		if (fq.count >= 64 || (r0 >= nsamples && fq.count > 0)) {   // stage 2: a round of followers
+		if (fq.count >= 64 || (r0 >= hi && fq.count > 0)) {   // stage 2: a round of followers
 			const uint32_t cnt = min(fq.count, 64u);
 			const bool act = lane < cnt;
 			const uint32_t s0 = act ? fq.start[lane] : 0u, nd = act ? fq.node[lane] : 0u;
@@ -1076,30 +1100,149 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g)
 			stage2_round(a, t, row, s0, nd, rn, act, lane, dbg_levels);
 			continue;
 		}
-		if (r0 >= nsamples)
+		if (r0 >= hi)
 			break;
 		const uint32_t idx = r0 + lane;
-		const bool act = idx < nsamples;
-		uint32_t slot = 0, before = 0;
+		const bool act = idx < hi;
+		uint32_t tslot = 0, before = 0;
 #pragma unroll
 		for (uint32_t k = 1; k < kTilesPerChecker; k++) {
-			slot += idx >= cum[k] ? 1u : 0u;
-			before = idx >= cum[k] ? cum[k] : before;
+			tslot += idx >= bc.cum[k] ? 1u : 0u;
+			before = idx >= bc.cum[k] ? bc.cum[k] : before;
 		}
 		uint2 it = make_uint2(0, 0);
 		if (act)
-			it = *sample_slot(a, tile0 + slot, idx - before);
+			it = *sample_slot(a, tile0 + tslot, idx - before);
+		if (!placed) {
+			// (hits of this sub-row lie at or behind its first sample's position less W, one per position:
+			// the span of its samples + the longest pattern + W entries are enough, sub_k allows for that)
+			const uint32_t p_first = (uint32_t)__builtin_amdgcn_readlane((int)it.x, 0);
+			row.lbase += (p_first - tile0 * a.tile_bytes) + j * a.sub_k;
+			t.room = (blk + 2) * a.cap - row.lbase;
+			placed = true;
+		}
 		dbg_rounds++;
-		dbg_cands += min(nsamples - r0, 64u);
+		dbg_cands += min(hi - r0, 64u);
 		r0 += 64;
 		stage1_round<W>(a, fq, it.x, it.y, act, lane);
 	}
 	if (lane == 0)
-		write_summary(a, t, row);
+		write_summary(a, t, slot, j == 0 ? word7 : row.lbase);
 	if (stamp && lane == 0) {
 		stamp[4] = __builtin_amdgcn_s_memrealtime();
 		stamp[5] = ((unsigned long long)dbg_rounds << 32) | dbg_cands;
 		stamp[6] = ((unsigned long long)dbg_levels << 32);
+	}
+}
+
+// lane 0 asks, every lane gets the answer
+#define ACM_LANE0(expr)                                                    \
+	([&]() -> uint32_t {                                               \
+		uint32_t v_ = 0;                                           \
+		if (lane == 0)                                             \
+			v_ = (expr);                                       \
+		return (uint32_t)__builtin_amdgcn_readfirstlane((int)v_);  \
+	}())
+
+template <int W>
+__global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint32_t helpers)
+{
+	__shared__ uint32_t q2[3][kQ2Cap];
+	const uint32_t lane = threadIdx.x;
+	// The workgroups of a launch are dealt over the group's batches, a multiple of 8 each: workgroup ids
+	// go round the 8 XCDs, and block r of EVERY batch should land on the XCD whose bulk-kernel workgroup
+	// r read the block's tiles a moment ago -- its L2 still has them.  Per batch: the blocks, the
+	// workgroup of the serial walks, the helpers.
+	const uint32_t nblocks = g.common.nrows - 1;
+	const bool serial = helpers == 0;   // no helpers launched (the last batches were not sample-heavy): every block does all of its sub-rows itself
+	const uint32_t nhelp = helpers;
+	const uint32_t per = (nblocks + 1 + nhelp + 7u) & ~7u, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
+	if (blk > nblocks + nhelp)
+		return;
+	const SieveArgs a = batch_view(g, bi);
+	if (blk == nblocks) {
+		if (threadIdx.x == 0)
+			side_walks(a);
+		return;
+	}
+	unsigned long long *stamp = a.stamps && blk < nblocks ? a.stamps + (size_t)(blk + 8192) * 8 : nullptr;
+	if (stamp && lane == 0)
+		stamp[0] = __builtin_amdgcn_s_memrealtime();
+	BlockCounts bc;
+	bool own = blk < nblocks;   // a block's wave starts with the block's own row = sub-row 0
+	uint32_t own_extra = 0;
+	if (own) {
+		load_counts(a, blk, lane, bc);
+		const uint32_t ns = bc.cum[kTilesPerChecker];
+		own_extra = ns > kSubRow ? (ns + kSubRow - 1) / kSubRow - 1 : 0u;
+	}
+	// The sub-rows behind the first of every block, numbered through the batch in block order (helpers;
+	// in the serial mode the blocks' waves).  A lane takes eight neighbouring blocks (sixty-four tiles:
+	// the text has at most 4096), the wave's prefix sum gives each block the number of its first sub-row.
+	uint32_t extra[8], first[8], mine = 0, base = 0, all = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 8; i++)
+		extra[i] = first[i] = 0;
+	if (!own || (serial && own_extra)) {
+		const uint4 *sc = (const uint4 *)a.scount;
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++) {
+			const uint32_t t0 = (lane * 8 + i) * kTilesPerChecker;
+			uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+			if (t0 < a.ntiles) {   // (the counts behind the last tile are whatever they are: masked below)
+				lo = sc[t0 / 4];
+				hi = sc[t0 / 4 + 1];
+			}
+			const uint32_t c[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+			uint32_t ns = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++)
+				ns += t0 + k < a.ntiles ? c[k] : 0u;
+			extra[i] = ns > kSubRow ? (ns + kSubRow - 1) / kSubRow - 1 : 0u;
+			first[i] = mine;
+			mine += extra[i];
+		}
+		base = wave_excl_sum(mine, lane, all);
+	}
+	// one loop for everything a wave does, so that the two stages are in the kernel once
+	const uint32_t step = serial ? 1u : nhelp;
+	uint32_t s0 = serial ? 0u : blk - nblocks - 1;
+	for (bool numbered = false;;) {
+		uint32_t tb = blk, tj = 0, tslot = blk + 1, tword7 = own_extra;
+		if (!own) {
+			if (numbered)
+				s0 += step;
+			numbered = true;
+			if (s0 >= all)
+				return;
+			// sub-row number s0 -> its block and index: the lane whose blocks hold it says so
+			uint32_t fb = 0, fk = 0;
+			bool found = false;
+#pragma unroll
+			for (uint32_t i = 0; i < 8; i++) {
+				const uint32_t lo = base + first[i];
+				if (s0 >= lo && s0 < lo + extra[i]) {
+					found = true;
+					fb = lane * 8 + i;
+					fk = s0 - lo + 1;
+				}
+			}
+			const unsigned long long who = __ballot(found);
+			if (!who)
+				return;   // (cannot happen: every number below `all` belongs to a block)
+			const int src = (int)__builtin_ctzll(who);
+			tb = (uint32_t)__builtin_amdgcn_readlane((int)fb, src);
+			tj = (uint32_t)__builtin_amdgcn_readlane((int)fk, src);
+			if (serial && tb != blk)
+				continue;   // (serial mode: a block's wave does its own sub-rows only)
+			tslot = a.nrows + s0;
+			tword7 = 0;
+			load_counts(a, tb, lane, bc);
+		}
+		check_subrow<W>(a, q2, lane, tb, tj, tslot, tword7, bc, own ? stamp : nullptr);
+		if (own && !serial)
+			return;
+		own = false;
 	}
 }
 
@@ -1134,23 +1277,27 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 }
 
 // ------------------------------------------------------------------- K3 ---
-// Every workgroup works out the whole prefix (a thousand 32-byte summaries, L2 resident:
-// exclusive prefix max of the extents, exclusive prefix sum of what the shadow leaves of each
-// list) and copies its share of the records: a thread per output cell finds the cell's row by
-// binary search in LDS and moves one record, so that the stores of a wave lie side by side.  (The
-// owner of a row copying the row's records itself, one predicated store per possible record,
-// took three times as long: it is the instruction count of 1024 threads that matters here.)
+// Every workgroup works out the whole prefix (the 32-byte summaries, L2 resident: exclusive prefix
+// max of the extents, exclusive prefix sum of what the shadow leaves of each list) and copies its
+// share of the records: a thread per output cell finds the cell's row by binary search in LDS and
+// moves one record, so that the stores of a wave lie side by side.  (The owner of a row copying the
+// row's records itself, one predicated store per possible record, took three times as long: it is
+// the instruction count of 1024 threads that matters here.)
+// Rows in position order: the walker's, then block by block the block's own row and its sub-rows
+// (k_sieve_check), kEmitBlock rows a round -- one round unless the text is sample-heavy.
 __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 {
 	const uint32_t per = gridDim.x / g.count, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
 	const SieveArgs a = batch_view(g, bi);
 	__shared__ uint32_t lds[kEmitBlock / 64];
-	__shared__ uint32_t s_base[kMaxRows + 1];   // first output cell of each row
-	__shared__ uint32_t s_drop[kMaxRows];       // shadowed head of each row's list
+	__shared__ uint32_t s_base[kEmitBlock + 1];   // first output cell of each row of the round
+	__shared__ uint32_t s_drop[kEmitBlock];       // shadowed head of each row's list
+	__shared__ uint32_t s_slot[kEmitBlock], s_lbase[kEmitBlock];   // where each row keeps its hits (RowRef)
+	__shared__ uint32_t s_ord[kMaxRows + 1];      // static row -> its place in the order of all rows
+	__shared__ uint32_t s_first[kMaxRows];        // static row -> work-list index of its first sub-row
 	__shared__ unsigned long long s_alive;
-	__shared__ uint32_t s_samples;              // flagged samples of the batch
-	const uint32_t rows = a.nrows;
-	const uint32_t r0 = threadIdx.x * kRowsPerThread;
+	__shared__ uint32_t s_samples;                // flagged samples of the batch
+	const uint32_t statics = a.nrows, tid = threadIdx.x;
 	unsigned long long *stamp = a.stamps && threadIdx.x == 0 ? a.stamps + (size_t)(9000 + blk) * 8 : nullptr;
 	if (stamp)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -1158,89 +1305,102 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	// where it is first used: a fetch from the argument buffer in front of every phase)
 	asm volatile("" :: "s"(a.pat_plane), "s"(a.off_plane), "s"(a.plane_capacity), "s"(a.off_shift), "s"(a.lhead),
 	    "s"(a.lists), "s"(a.cap), "s"(a.misc), "s"(a.dev2ref), "s"(a.path_marker), "s"(a.giveups), "s"(a.n));
-	if (threadIdx.x == 0) {
+	if (tid == 0) {
 		s_alive = ~0ull;
 		s_samples = 0;
 	}
-	uint32_t my_samples = 0;
-	uint32_t E[kRowsPerThread], cnt[kRowsPerThread], first[kRowsPerThread], last[kRowsPerThread];
-	uint32_t tmax = 0;
-	bool gave = false;
-	unsigned long long alive = ~0ull;
-#pragma unroll
-	for (uint32_t i = 0; i < kRowsPerThread; i++) {
-		const uint32_t r = r0 + i, rc = min(r, rows - 1);   // (loads without a branch around them: in flight together)
-		uint4 s = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords);
-		uint4 al = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords + 4);   // alive key, node, samples
-		if (r >= rows) {
-			s = make_uint4(0, 0, 0, 0);
-			al = make_uint4(0, 0, 0, 0);
+	static_assert(kMaxRows <= kEmitBlock, "a thread per static row");
+	// the static rows' summaries, a thread each (loads without a branch around them: in flight together)
+	uint4 s0, al0;
+	{
+		const uint32_t rc = min(tid, statics - 1);
+		s0 = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords);
+		al0 = *(const uint4 *)(a.summary + (size_t)rc * kSummaryWords + 4);   // alive key, node, samples, sub-rows
+		if (tid >= statics) {
+			s0 = make_uint4(0, 0, 0, 0);
+			al0 = make_uint4(0, 0, 0, 0);
 		}
-		my_samples += al.z;
-		E[i] = s.x;
-		cnt[i] = s.y;
-		first[i] = s.z;
-		last[i] = s.w;
-		gave |= s.y == kGaveUp;
-		tmax = max(tmax, s.x);
-		if (al.x)
-			alive = min(alive, ((unsigned long long)al.x << 32) | al.y);
 	}
-	if (__syncthreads_or(gave ? 1 : 0)) {   // cannot happen (geometry_for): say so instead of writing planes
-		if (blk == 0 && threadIdx.x == 0) {
-			*a.path_marker = kMarkerFailed;
-			a.pat_plane[0] = a.off_plane[0] = 0;
-		}
-		return;
+	uint32_t my_samples = al0.z, rows_all;
+	const uint32_t extra = tid == 0 ? 0u : al0.w & 0xFFFFu;   // (row 0 is the walker's: its word says nothing)
+	const uint32_t ord = block_exclusive<false>(tid < statics ? 1u + extra : 0u, lds, &rows_all);
+	if (tid < statics) {
+		s_ord[tid] = ord;
+		s_first[tid] = ord - tid;   // sub-rows of the blocks in front: the number of this block's first (k_sieve_check)
 	}
-	if (alive != ~0ull)
-		atomicMin(&s_alive, alive);
+	if (tid == 0)
+		s_ord[statics] = rows_all;
 	if (blk == 0) {   // (a wave at a time: five hundred atomics on one LDS word would take longer than the copy below)
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1)
 			my_samples += __shfl_xor(my_samples, o, 64);
-		if ((threadIdx.x & 63) == 0 && my_samples)
+		if ((tid & 63) == 0 && my_samples)
 			atomicAdd(&s_samples, my_samples);
 	}
+	__syncthreads();
 	if (stamp)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
-	uint32_t all_max, all_cells;
-	uint32_t carry = block_exclusive<true>(tmax, lds, &all_max);
-	uint32_t drop[kRowsPerThread], kept_sum = 0;
-#pragma unroll
-	for (uint32_t i = 0; i < kRowsPerThread; i++) {
+	const bool plain = rows_all == statics;   // no sub-rows: row = thread, everything is loaded already
+	uint32_t carry_in = 0, cell_in = 0;
+	unsigned long long alive = ~0ull;
+	bool gave_any = false;
+	for (uint32_t o0 = 0; o0 < rows_all; o0 += kEmitBlock) {
+		const uint32_t o = o0 + tid;
+		const bool have = o < rows_all;
+		uint4 su = s0, sa = al0;
+		RowRef rr;
+		rr.slot = tid;
+		rr.lbase = tid * a.cap;
+		if (!plain) {
+			// the static row this row belongs to: the last one whose place is not behind o
+			uint32_t lo = 0, hi = statics;
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_ord[mid] <= o)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			const uint32_t k = o - s_ord[lo];
+			rr.slot = k == 0 ? lo : statics + s_first[lo] + k - 1;
+			rr.lbase = lo * a.cap;
+			su = make_uint4(0, 0, 0, 0);
+			sa = make_uint4(0, 0, 0, 0);
+			if (have) {
+				su = *(const uint4 *)(a.summary + (size_t)rr.slot * kSummaryWords);
+				sa = *(const uint4 *)(a.summary + (size_t)rr.slot * kSummaryWords + 4);
+				if (k)
+					rr.lbase = sa.w;
+			}
+		}
+		const uint32_t E = su.x, cnt = su.y == kGaveUp ? 0u : su.y, first = su.z, last = su.w;
+		gave_any |= su.y == kGaveUp;
+		if (have && sa.x)
+			alive = min(alive, ((unsigned long long)sa.x << 32) | sa.y);
+		uint32_t all_max, all_cells;
+		const uint32_t carry = max(carry_in, block_exclusive<true>(have ? E : 0u, lds, &all_max));
 		uint32_t d = 0;
-		if (cnt[i] && first[i] < carry) {
-			if (last[i] < carry) {
-				d = cnt[i];
+		if (have && cnt && first < carry) {
+			if (last < carry) {
+				d = cnt;
 			} else {
-				while (d < cnt[i] && hit_slot(a, r0 + i, d)->x < carry)
+				while (d < cnt && hit_slot(a, rr, d)->x < carry)
 					d++;
 			}
 		}
-		drop[i] = d;
-		kept_sum += cnt[i] - d;
-		carry = max(carry, E[i]);
-	}
-	uint32_t cell = block_exclusive<false>(kept_sum, lds, &all_cells);
-	if (stamp)
-		stamp[2] = __builtin_amdgcn_s_memrealtime();
-	{
-#pragma unroll
-		for (uint32_t i = 0; i < kRowsPerThread; i++) {
-			const uint32_t r = r0 + i;
-			if (r < rows) {
-				s_base[r] = cell;
-				s_drop[r] = drop[i];
-				cell += cnt[i] - drop[i];
-			}
-		}
-		if (threadIdx.x == 0)
-			s_base[rows] = all_cells;
+		const uint32_t kept = have ? cnt - d : 0u;
+		const uint32_t cell = cell_in + block_exclusive<false>(kept, lds, &all_cells);
+		s_base[tid] = cell;
+		s_drop[tid] = d;
+		s_slot[tid] = rr.slot;
+		s_lbase[tid] = rr.lbase;
+		if (tid == 0)
+			s_base[kEmitBlock] = cell_in + all_cells;
 		__syncthreads();
-		// one thread per output cell: find the row it belongs to, copy the record
-		for (uint32_t c = blk * kEmitBlock + threadIdx.x; c < all_cells; c += per * kEmitBlock) {
-			uint32_t lo = 0, hi = rows;   // the row r with s_base[r] <= c < s_base[r + 1]
+		// one thread per output cell of the round: find the row it belongs to, copy the record
+		const uint32_t rows_here = min(rows_all - o0, (uint32_t)kEmitBlock), cell_end = cell_in + all_cells;
+		for (uint32_t c = cell_in + blk * kEmitBlock + tid; c < cell_end; c += per * kEmitBlock) {
+			uint32_t lo = 0, hi = rows_here;   // the row r with s_base[r] <= c < s_base[r + 1]
 			while (hi - lo > 1) {
 				const uint32_t mid = (lo + hi) >> 1;
 				if (s_base[mid] <= c)
@@ -1248,16 +1408,33 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 				else
 					hi = mid;
 			}
-			const uint2 rec = *hit_slot(a, lo, s_drop[lo] + (c - s_base[lo]));
+			RowRef from;
+			from.slot = s_slot[lo];
+			from.lbase = s_lbase[lo];
+			const uint2 rec = *hit_slot(a, from, s_drop[lo] + (c - s_base[lo]));
 			if (c + 2 < a.plane_capacity) {
 				a.pat_plane[1 + c] = (int32_t)rec.y;
 				a.off_plane[1 + c] = (int32_t)rec.x + a.off_shift;
 			}
 		}
+		carry_in = max(carry_in, all_max);
+		cell_in = cell_end;
+		__syncthreads();
 	}
+	if (__syncthreads_or(gave_any ? 1 : 0)) {   // cannot happen (geometry_for): say so instead of leaving planes that look complete
+		if (blk == 0 && tid == 0) {
+			*a.path_marker = kMarkerFailed;
+			a.pat_plane[0] = a.off_plane[0] = 0;
+		}
+		return;
+	}
+	if (alive != ~0ull)
+		atomicMin(&s_alive, alive);
+	__syncthreads();
 	if (stamp)
 		stamp[3] = __builtin_amdgcn_s_memrealtime();
-	if (blk == 0 && threadIdx.x == 0) {   // header and trailer cells
+	if (blk == 0 && tid == 0) {   // header and trailer cells
+		const uint32_t all_cells = cell_in;
 		const unsigned long long k = s_alive;
 		const uint32_t last_dev = k != ~0ull ? (uint32_t)k : a.misc[0];
 		const int32_t last_ref = (int32_t)a.dev2ref[last_dev];
@@ -1272,6 +1449,8 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		// a batch this dense in matches, or with this many samples for the check kernel to look at (real
 		// binaries: common 3-grams of code), is the chain pipeline's: AUTO mode counts them (scan.hip,
 		// pick_sparse)
+		if (a.giveups)   // what the host sizes the next check launches by (sparse_group_enqueue)
+			__hip_atomic_store(a.giveups + 1, s_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		if (a.giveups && (all_cells > a.n / kDenseDivisor || s_samples > a.n / kBusyDivisor))
 			__hip_atomic_fetch_add(a.giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
@@ -1282,7 +1461,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
 
 struct Geometry {
-	uint32_t tile_bytes, ntiles, cap, scap, nrows;
+	uint32_t tile_bytes, ntiles, cap, scap, nrows, sub_k, max_extra;
 };
 
 // Nothing overflows: a tile's sample list has room for every sample of the tile, a row's hit list
@@ -1296,8 +1475,12 @@ Geometry geometry_for(const acm_dfa *d, size_t n)
 		g.tile_bytes *= 2;
 	g.ntiles = (uint32_t)((n + g.tile_bytes - 1) / g.tile_bytes);
 	g.nrows = (g.ntiles + kTilesPerChecker - 1) / kTilesPerChecker + 1;
-	g.cap = kTilesPerChecker * g.tile_bytes + d->max_pattern_len + 8;
 	g.scap = g.tile_bytes / (d->sv_stride ? d->sv_stride : 1);
+	// sub-rows (k_sieve_check): a block has at most maxsub, each needs sub_k entries beyond its span
+	g.sub_k = d->max_pattern_len + (d->sv_stride ? d->sv_stride : 1) + 8;
+	const uint32_t maxsub = (kTilesPerChecker * g.scap + kSubRow - 1) / kSubRow;
+	g.cap = kTilesPerChecker * g.tile_bytes + maxsub * g.sub_k + 8;
+	g.max_extra = (uint32_t)(((size_t)g.ntiles * g.scap + kSubRow - 1) / kSubRow) + 1;
 	return g;
 }
 
@@ -1310,11 +1493,12 @@ size_t workspace_for_exactly(const acm_dfa *d, size_t n)
 {
 	const Geometry g = geometry_for(d, n);   // tile size and cap grow with the text, the tile count is bounded
 	size_t o = 0;
-	o += align_up((size_t)kMaxRows * kSummaryWords * 4, 256);
+	const size_t rows_max = (size_t)g.nrows + g.max_extra;
+	o += align_up(rows_max * kSummaryWords * 4, 256);
 	o += align_up((size_t)g.nrows * g.cap * 8, 256);
 	o += align_up((size_t)g.ntiles * g.scap * 8 + 64, 256);
 	o += align_up((size_t)kMaxTiles * kSampleHead * 8, 256);
-	o += align_up((size_t)(kMaxRows + kRowsPerThread) * kHitHead * 8, 256);
+	o += align_up((rows_max + 4) * kHitHead * 8, 256);
 	o += align_up((size_t)kMaxTiles * 4, 256);
 	o += 256;
 	return o;
@@ -1382,6 +1566,8 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.ntiles = g.ntiles;
 	a.cap = g.cap;
 	a.nrows = g.nrows;
+	a.max_extra = g.max_extra;
+	a.sub_k = g.sub_k;
 	a.scap = g.scap;
 	a.giveups = d->d_giveups;
 	size_t o = 0;
@@ -1390,11 +1576,12 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 		o += align_up(bytes, 256);
 		return at;
 	};
-	grp.o_summary = take((size_t)kMaxRows * kSummaryWords * 4);
+	const size_t rows_max = (size_t)g.nrows + g.max_extra;
+	grp.o_summary = take(rows_max * kSummaryWords * 4);
 	grp.o_lists = take((size_t)g.nrows * g.cap * 8);
 	grp.o_samples = take((size_t)g.ntiles * g.scap * 8);
 	grp.o_shead = take((size_t)g.ntiles * kSampleHead * 8);
-	grp.o_lhead = take((size_t)(g.nrows + kRowsPerThread) * kHitHead * 8);
+	grp.o_lhead = take((rows_max + 4) * kHitHead * 8);
 	grp.o_scount = take((size_t)g.ntiles * 4);
 	grp.o_misc = take(256);
 }
@@ -1457,7 +1644,16 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		blocks = (uint32_t)d->num_cus;
 	// K2: a wave per kTilesPerChecker tiles, and one workgroup for the serial walks
 	const uint32_t cwaves = g.nrows - 1;
-	const uint32_t cblocks = (cwaves + 1 + 7u) & ~7u;   // (a multiple of 8 per batch: k_sieve_check)
+	// Helper waves for the sub-rows of sample-heavy blocks only where the text is like that: the emit
+	// kernel leaves the batch's sample count in pinned host memory, and a launch whose stream's last batch
+	// had more than a flagged sample per 512 bytes gets them (the blocks' waves do their sub-rows
+	// themselves otherwise -- the first heavy batch after quiet ones is slow).  On quiet text 512 more
+	// workgroups per batch, each reading the batch's 4096 tile counts, cost a launch group of sixteen 20 us.
+	static const char *force = getenv("ACM_SIEVE_HELPERS");   // debugging aid: "0" never, anything else always
+	const uint32_t seen = d->h_giveups ? ((volatile uint32_t *)d->h_giveups)[1] : 0u;
+	const bool heavy = force ? force[0] != '0' : seen > n / kHeavyDivisor;
+	const uint32_t helpers = heavy ? kHelperWaves : 0u;
+	const uint32_t cblocks = (cwaves + 1 + helpers + 7u) & ~7u;   // (a multiple of 8 per batch: k_sieve_check)
 	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
 	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)
 		eblocks *= 2;
@@ -1492,10 +1688,10 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	if (after_sieve)
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
 	switch (d->sv_stride) {
-	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
-	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
-	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
-	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp); break;
+	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
+	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
+	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
+	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
 	}
 	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
 	if (after_emit)
