@@ -13,7 +13,7 @@
 //                  the sentiment corpus) a second trip through a wave-uniform loop.  A transition into
 //                  a final state stores {state code, step} in the lane's own list of the tile's staging
 //                  area, lists of the 64 lanes interleaved so that the k-th records lie side by side.
-//   k_lds_scatter  per 256 chains: scan of the counts on top of the totals of the tiles in front,
+//   k_lds_scatter  per 1024 chains: scan of the counts on top of the totals of the tiles in front,
 //                  records copied to their final, position-ordered cells with the pattern looked up,
 //                  header and trailer cells.
 // Both kernels take a GROUP of up to 16 batches of one size (acm_scan_batches_async): the image is
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_lds_walk(LdsGroup g)
 	}
 }
 
-// Ordered scatter: a workgroup per 256 chains of one batch.
+// Ordered scatter: a workgroup per 1024 chains of one batch.
 template <int C>
 __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 {

@@ -95,7 +95,9 @@ constexpr uint32_t kGaveUp = 0xFFFFFFFFu;  // hit count of a tile whose list was
 constexpr uint32_t kMarkerFailed = 0xDEADu; // path marker of a scan that did not produce planes
 constexpr uint32_t kDenseDivisor = 128;    // more than a record per this many bytes: a dense batch
 constexpr uint32_t kHeavyDivisor = 512;    // more than a flagged sample per this many bytes: the next launches get helper waves (k_sieve_check)
-constexpr uint32_t kBusyDivisor = 256;     // ... or a flagged sample per this many: the check kernel's time, not the bulk kernel's, is the batch's
+constexpr uint32_t kBusyDivisor = 48;      // ... or a flagged sample per this many: the check kernel's time, not the bulk kernel's, is the batch's
+                                           // (with helper waves the sparse pipeline keeps up with the chain pipeline's 70..95 us to about 700 k samples
+                                           // per 32 MiB: 62 us at 447 k, 91 at 650 k, 106 at 983 k -- tools/real_data_probe.py)
 constexpr int kEmitBlock = 1024;
 constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // static rows: the carried-state walker + a block of eight tiles each
 // A block whose tiles hold more flagged samples than this (real binaries: the 3-grams of code and tables
@@ -105,7 +107,9 @@ constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // static rows
 // out for itself from the tiles' sample counts, as the emit kernel does from the rows' summaries.  To
 // the emit kernel a sub-row is a row like any other.
 constexpr uint32_t kSubRow = 256;
-constexpr uint32_t kHelperWaves = 512;     // waves per batch that do nothing but sub-rows (they leave at once when there are none)
+constexpr uint32_t kSubRowMin = 128;       // the smallest ACM_SIEVE_SUBROW (debugging aid) may ask for: the workspace is laid out for it
+constexpr uint32_t kHelperWaves = 2048;    // waves per batch that do nothing but sub-rows, launched for sample-heavy streams only (512: 212 us for the
+                                           // worst 32 MiB of a real binary x 15000 signatures, 1024: 147, 2048: 106; sub-rows of 128 samples: no better)
 
 struct SieveArgs {
 	// tables
@@ -136,6 +140,7 @@ struct SieveArgs {
 	// geometry
 	uint32_t tile_bytes, ntiles, cap, nrows;   // nrows: static rows = blocks of eight tiles + 1 (the walker's)
 	uint32_t max_extra, sub_k;                 // sub-rows a text can have at most; list room a sub-row needs on top of its span
+	uint32_t subrow;                           // samples of a sub-row (kSubRow)
 	// workspace
 	uint2 *shead, *lhead;   // [ntiles][kSampleHead], [nrows][kHitHead]: the first entries of the lists below
 	uint2 *samples;      // [ntiles][scap] {position, 3-gram} of the samples the filter flagged, ascending
@@ -1049,7 +1054,7 @@ __device__ __forceinline__ void check_subrow(const SieveArgs &a, uint32_t (*q2)[
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
 	const uint32_t ns = bc.cum[kTilesPerChecker];
-	const uint32_t lo = j * kSubRow, hi = min(ns, lo + kSubRow);
+	const uint32_t lo = j * a.subrow, hi = min(ns, lo + a.subrow);
 	t.samples = j == 0 ? ns : 0u;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
 	// the block's list region; a sub-row's part of it starts where its first sample lies, plus the room
 	// the sub-rows in front need beyond their spans (set below, once that sample is known)
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 	if (own) {
 		load_counts(a, blk, lane, bc);
 		const uint32_t ns = bc.cum[kTilesPerChecker];
-		own_extra = ns > kSubRow ? (ns + kSubRow - 1) / kSubRow - 1 : 0u;
+		own_extra = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
 	}
 	// The sub-rows behind the first of every block, numbered through the batch in block order (helpers;
 	// in the serial mode the blocks' waves).  A lane takes eight neighbouring blocks (sixty-four tiles:
@@ -1198,7 +1203,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 #pragma unroll
 			for (uint32_t k = 0; k < 8; k++)
 				ns += t0 + k < a.ntiles ? c[k] : 0u;
-			extra[i] = ns > kSubRow ? (ns + kSubRow - 1) / kSubRow - 1 : 0u;
+			extra[i] = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
 			first[i] = mine;
 			mine += extra[i];
 		}
@@ -1478,9 +1483,9 @@ Geometry geometry_for(const acm_dfa *d, size_t n)
 	g.scap = g.tile_bytes / (d->sv_stride ? d->sv_stride : 1);
 	// sub-rows (k_sieve_check): a block has at most maxsub, each needs sub_k entries beyond its span
 	g.sub_k = d->max_pattern_len + (d->sv_stride ? d->sv_stride : 1) + 8;
-	const uint32_t maxsub = (kTilesPerChecker * g.scap + kSubRow - 1) / kSubRow;
+	const uint32_t maxsub = (kTilesPerChecker * g.scap + kSubRowMin - 1) / kSubRowMin;
 	g.cap = kTilesPerChecker * g.tile_bytes + maxsub * g.sub_k + 8;
-	g.max_extra = (uint32_t)(((size_t)g.ntiles * g.scap + kSubRow - 1) / kSubRow) + 1;
+	g.max_extra = (uint32_t)(((size_t)g.ntiles * g.scap + kSubRowMin - 1) / kSubRowMin) + 1;
 	return g;
 }
 
@@ -1568,6 +1573,8 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.nrows = g.nrows;
 	a.max_extra = g.max_extra;
 	a.sub_k = g.sub_k;
+	static const uint32_t subrow = getenv("ACM_SIEVE_SUBROW") ? std::max<uint32_t>(kSubRowMin, (uint32_t)atoi(getenv("ACM_SIEVE_SUBROW"))) : kSubRow;
+	a.subrow = subrow;
 	a.scap = g.scap;
 	a.giveups = d->d_giveups;
 	size_t o = 0;
@@ -1652,7 +1659,8 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	static const char *force = getenv("ACM_SIEVE_HELPERS");   // debugging aid: "0" never, anything else always
 	const uint32_t seen = d->h_giveups ? ((volatile uint32_t *)d->h_giveups)[1] : 0u;
 	const bool heavy = force ? force[0] != '0' : seen > n / kHeavyDivisor;
-	const uint32_t helpers = heavy ? kHelperWaves : 0u;
+	static const uint32_t helper_waves = getenv("ACM_SIEVE_HELPER_WAVES") ? (uint32_t)atoi(getenv("ACM_SIEVE_HELPER_WAVES")) : kHelperWaves;   // debugging aid
+	const uint32_t helpers = heavy ? helper_waves : 0u;
 	const uint32_t cblocks = (cwaves + 1 + helpers + 7u) & ~7u;   // (a multiple of 8 per batch: k_sieve_check)
 	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
 	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)

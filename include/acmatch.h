@@ -280,7 +280,7 @@ int acm_scan_set_graphs(acm_dfa *, int enable);
  *           that is dense in matches
  *   AUTO    SPARSE when the pattern set allows it -- adaptively: when half of
  *           the last 16 sparse batches held more than a record per 128 bytes
- *           or more than a flagged sample per 256 (real binaries) the next 64
+ *           or more than a flagged sample per 48 (the worst of real binaries) the next 64
  *           go to the chain pipeline; then the sparse one is tried again, 4
  *           batches at a time, and every bad look quadruples the chain
  *           pipeline's share (up to 4096 batches)

@@ -369,7 +369,7 @@ def test_auto_mode_hands_dense_batches_to_the_chain_pipeline(gpu):
 def test_auto_mode_counts_sample_heavy_batches(gpu):
     """AUTO also leaves the sparse pipeline for texts without a single match whose sampled 3-grams
     keep hitting the pattern set (real binaries: common 3-grams of code and tables): more than a
-    flagged sample per 256 bytes is the check kernel's time, not the bulk kernel's."""
+    flagged sample per 48 bytes is more than the check kernel's helper waves keep up with."""
     pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 400)
     a, o = build(pats)
     n = 1 << 20
