@@ -450,8 +450,19 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                                workspace=(wss[w][0], ws_bytes))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # ... and the copies alone, same buffers and streams: what the link gives (the ceiling of the figure above)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(ne):
+            w = k % We
+            with torch.cuda.stream(streams[w]):
+                stage[w][:n_local].copy_(pinned[k % len(pinned)], non_blocking=True)
+        torch.cuda.synchronize()
+        dt_copy = time.perf_counter() - t0
         e2e = {"value": round(SHARD * ne / dt / 1e9, 2), "unit": "GB/s", "steps": ne,
-               "what": "pinned host buffer -> hipMemcpyAsync -> scan, %d streams; PCIe included, file I/O not" % We}
+               "h2d_only": round(SHARD * ne / dt_copy / 1e9, 2),
+               "what": "pinned host buffer -> hipMemcpyAsync -> scan, %d streams; PCIe included, file I/O not; "
+                       "h2d_only: the same copies without the scans" % We}
 
     # ---- parity: the planes of the last steps of the last block, every distinct text once -----------
     owner = {slot_of(k): k for k in range(K)}            # the last step that wrote each slot

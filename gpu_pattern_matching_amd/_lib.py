@@ -24,7 +24,7 @@ class ScanBatch(C.Structure):
                 ("init_state", C.c_long), ("d_workspace", _vp), ("workspace_bytes", C.c_size_t),
                 ("d_pat_plane", _vp), ("d_off_plane", _vp), ("plane_capacity", C.c_size_t),
                 ("stream", _vp), ("wait_before_walk", _vp), ("record_after_walk", _vp), ("report", C.c_int),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("d_init_plane", _vp), ("init_plane_capacity", C.c_size_t)]
 
 
 class ShardPlan(C.Structure):
@@ -101,6 +101,7 @@ NATIVE_API = {
     "acm_remap_offsets": (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "acm_shard_plan_for": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
     "acm_gather_planes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "acm_gather_planes_sized": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _i32p, _vp]),
     "acm_merge_planes": (C.c_long, [_vp, _vp, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "acm_rt_set_device": (C.c_int, [C.c_int]),
     "acm_rt_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),

@@ -254,12 +254,13 @@ class Matcher:
                                       else self.plane_capacity, st), "acm_scan_async")
 
     def make_batch(self, d_text, n, stream, pat_plane, off_plane, plane_capacity, workspace, init_state=0, halo=0,
-                   offset_shift=0, report=0, profile=False):
+                   offset_shift=0, report=0, profile=False, init_plane=None, init_plane_capacity=0):
         """A reusable acm_scan_batch for enqueue(): a worker that scans with the same buffers over and
         over builds its batches once and pays one foreign call per scan."""
         return _lib.ScanBatch(_ptr(d_text), n, halo, offset_shift, init_state, _ptr(workspace[0]), workspace[1],
                               _ptr(pat_plane), _ptr(off_plane), plane_capacity, stream, None, None, report,
-                              1 if profile else 0)
+                              1 if profile else 0, _ptr(init_plane) if init_plane is not None else None,
+                              init_plane_capacity)
 
     def enqueue(self, batch):
         rc = self.lib.acm_scan_batch_async(self.dfa, C.byref(batch))

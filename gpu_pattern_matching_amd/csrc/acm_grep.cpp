@@ -145,6 +145,8 @@ struct Buffer {   // one of the two staging buffers of a worker
 	void *d_packed = nullptr;
 	size_t chunks = 0, bytes = 0;
 	std::vector<int32_t> starts;
+	void *done = nullptr;        // event behind the buffer's last copy: collect() waits for this buffer, not for the stream
+	size_t scan_cap = 0;         // capacity its scan's planes were given (the next buffer reads its final state from them)
 };
 
 struct Worker {
@@ -251,8 +253,12 @@ size_t fill_text(Buffer &b, const Config &c, FILE *fp, int file_id, size_t *line
 	return total;
 }
 
-// enqueue copy-in, scan, bucket planes and copy-back of one buffer; no sync
-void submit(Worker &w, Buffer &b)
+// enqueue copy-in, scan, bucket planes and copy-back of one buffer; no sync.  prev: the worker's buffer
+// in front of this one if its results have not been collected yet -- the scan then starts in the state
+// that buffer's scan ended in, read from its planes ON THE DEVICE (acm_scan_batch.d_init_plane; the
+// reference carries it through the host, databuf.c:622): the GPU goes on with this buffer while the
+// host walks the previous one's results.
+void submit(Worker &w, Buffer &b, const Buffer *prev)
 {
 	const Config &c = w.sh->cfg;
 	const int chunks = (int)b.chunks;
@@ -279,20 +285,26 @@ void submit(Worker &w, Buffer &b)
 		text = b.d_packed;
 	}
 	int32_t *pat = (int32_t *)b.d_pat, *off = (int32_t *)b.d_off;
+	acm_scan_batch sb;
+	memset(&sb, 0, sizeof(sb));
+	sb.d_text = text;
+	sb.n = stream_len;
+	sb.init_state = w.last_state;
+	if (prev) {
+		sb.init_state = 0;
+		sb.d_init_plane = (const int32_t *)prev->d_pat;
+		sb.init_plane_capacity = prev->scan_cap;
+	}
+	sb.d_workspace = w.ws;
+	sb.workspace_bytes = w.ws_bytes;
+	sb.d_pat_plane = pat;
+	sb.d_off_plane = off;
+	sb.plane_capacity = cap;
+	sb.stream = s;
+	b.scan_cap = cap;
 	if (!c.all_patterns) {
-		CK(acm_scan_async(w.dfa, text, stream_len, w.last_state, w.ws, w.ws_bytes, pat, off, cap, s));
+		CK(acm_scan_batch_async(w.dfa, &sb));
 	} else {   // final states instead of head patterns, then every pattern of each state's match list
-		acm_scan_batch sb;
-		memset(&sb, 0, sizeof(sb));
-		sb.d_text = text;
-		sb.n = stream_len;
-		sb.init_state = w.last_state;
-		sb.d_workspace = w.ws;
-		sb.workspace_bytes = w.ws_bytes;
-		sb.d_pat_plane = pat;
-		sb.d_off_plane = off;
-		sb.plane_capacity = cap;
-		sb.stream = s;
 		sb.report = ACM_REPORT_STATE;
 		CK(acm_scan_batch_async(w.dfa, &sb));
 		CK(acm_expand_matches_async(w.dfa, pat, off, cap - 2, (int32_t *)b.d_pat_all, (int32_t *)b.d_off_all,
@@ -310,13 +322,16 @@ void submit(Worker &w, Buffer &b)
 	const size_t cells = (size_t)c.max_results * chunks + 1;
 	CK(acm_rt_memcpy_d2h(b.h_results, b.d_results, cells * 4, s));
 	CK(acm_rt_memcpy_d2h(b.h_results2, b.d_results2, cells * 4, s));
+	if (!b.done)
+		CK(acm_rt_event_create(&b.done));
+	CK(acm_rt_event_record(b.done, s));
 }
 
 // wait for the buffer, walk the bucket planes (databuf.c:747-782), print -v lines
 void collect(Worker &w, Buffer &b)
 {
 	const Config &c = w.sh->cfg;
-	CK(acm_rt_stream_sync(w.stream));
+	CK(acm_rt_event_sync(b.done));   // (this buffer's copies; the next buffer's scan may still be running)
 	if (c.all_patterns && b.h_all_count && (size_t)*b.h_all_count > b.all_cap - 2) {
 		fprintf(stderr, "ERROR: -A produced %d records for one buffer, the planes hold %zu; use a smaller -G/-B\n",
 		    *b.h_all_count, b.all_cap - 2);
@@ -421,10 +436,11 @@ void *worker_main(void *arg)
 		}
 		const bool last = cur >= nfiles || g_terminate;
 		if (b.chunks > 0 && (full || last || (c.follow && file_done))) {
-			// the scan needs the state the previous buffer ended in
+			// the scan starts in the state the previous buffer ended in: taken from that buffer's planes on
+			// the device, so this one is enqueued BEFORE the host waits for the previous one and walks its results
+			submit(w, b, in_flight ? &w.buf[filling ^ 1] : nullptr);   // GPU works on b while we read into the other buffer
 			if (in_flight)
 				collect(w, w.buf[filling ^ 1]);
-			submit(w, b);   // GPU works on b while we read into the other buffer
 			in_flight = true;
 			filling ^= 1;
 		}

@@ -24,6 +24,7 @@ struct acm_dfa {
 	uint16_t *d_hot = nullptr;           // [hot_rows][stride]
 	int32_t *d_out = nullptr;            // [states] reported pattern index
 	uint32_t *d_dev2ref = nullptr;       // [states]
+	uint32_t *d_ref2dev = nullptr;       // [states] the other way: a final state handed over on the device (acm_scan_batch.d_init_plane)
 	uint8_t *d_in_byte = nullptr;        // [states + 224] byte on the edge into dev state
 	uint16_t *d_depth = nullptr;         // [states] trie depth of each state (carried-state walker of the sparse pipeline)
 
@@ -58,6 +59,7 @@ struct acm_dfa {
 	uint8_t *d_lds_image = nullptr;      // what the walk kernel copies to LDS
 	int32_t *d_lds_out = nullptr;        // [compact id] reported pattern index
 	uint32_t *d_lds_cid2ref = nullptr;   // [compact id] reference id
+	uint32_t *d_lds_ref2code = nullptr;  // [reference id] state code (a state handed over on the device)
 	uint32_t lds_image_bytes = 0, lds_off_rec = 0, lds_halo = 0, lds_rows = 0;
 	std::vector<uint16_t> lds_ref2code;  // host: state code of a reference id (init_state)
 
@@ -79,6 +81,8 @@ struct acm_dfa {
 		void *pat_plane, *off_plane;
 		size_t plane_capacity;
 		int report, mode, chain_bytes, chains_per_lane;
+		const void *init_plane;
+		size_t init_plane_capacity;
 	};
 	struct GraphEntry {
 		GraphKey key;

@@ -330,6 +330,7 @@ extern "C" int acm_dfa_upload(const acm_automaton *a, int device, acm_dfa **out)
 		if (rc == ACM_OK)
 			rc = upload_small(d, &d->d_dev2ref, a->dev2ref.data(), a->dev2ref.size());
 		if (rc == ACM_OK) rc = upload_small(d, &d->d_in_byte, inb.data(), inb.size());
+		if (rc == ACM_OK) rc = upload_small(d, &d->d_ref2dev, a->ref2dev.data(), a->ref2dev.size());
 
 		if (rc == ACM_OK) {
 			std::vector<uint16_t> dep(n);
@@ -400,6 +401,7 @@ extern "C" void acm_dfa_release(acm_dfa *d)
 		free_small(d, d->d_out);
 		free_small(d, d->d_dev2ref);
 		free_small(d, d->d_in_byte);
+		free_small(d, d->d_ref2dev);
 		hipFree(d->d_list_begin);
 		hipFree(d->d_list_len);
 		hipFree(d->d_list_pool);

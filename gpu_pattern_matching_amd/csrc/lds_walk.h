@@ -25,6 +25,7 @@ struct LdsJob {
 	uint8_t *cnt;           // cnt_bytes
 	uint32_t *tile_total;   // tile_words
 	uint32_t *misc;         // [0] last state code, [2] path marker
+	const uint32_t *init_ptr;   // null, or where the code of the state to start in is (handed over on the device)
 };
 void lds_walk_needs(const acm_dfa *d, size_t n, size_t *stage_words, size_t *cnt_bytes, size_t *tile_words);
 uint32_t lds_walk_max_group();

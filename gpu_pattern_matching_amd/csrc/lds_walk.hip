@@ -51,6 +51,7 @@ struct LdsBatch {
 	uint32_t init_code, drop_before;
 	int32_t off_shift;
 	uint32_t plane_capacity, report_state;
+	const uint32_t *init_ptr;   // not null: the code of the state to start in is there (handed over on the device)
 };
 
 struct LdsGroup {
@@ -383,7 +384,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		drain<false>(lds, off_rec, w[1].w, e[1], nd[1], so[1], stage, 0);
 	}
 	if (chain[0] == 0)
-		e[0] = b.init_code;   // the text's first chain starts at byte 0, in the carried-in state
+		e[0] = b.init_ptr ? *b.init_ptr : b.init_code;   // the text's first chain starts at byte 0, in the carried-in state
 #pragma nounroll
 	for (uint32_t gi = hg; gi < groups; gi++) {
 		ACM_PICK(gi);
@@ -437,7 +438,7 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 		hi[c] = (int32_t)(hb + len);
 		// records in front of drop_before belong to the shard's halo (acm_scan_shard_async)
 		keep[c] = (int32_t)hb + (b.drop_before > base ? (int32_t)min(b.drop_before - base, kChainBytes) : 0);
-		e[c] = base <= hb ? b.init_code : 0u;   // a chain this close to the start begins at byte 0, in the carried-in state
+		e[c] = base <= hb ? (b.init_ptr ? *b.init_ptr : b.init_code) : 0u;   // a chain this close to the start begins at byte 0, in the carried-in state
 		so0[c] = so[c] = (uint32_t)c * (kChainBytes * 64) + lane;
 		// all of the lane's text up front, a chain's loads back to back (scan.hip, walk_tile PRE: taken a
 		// group per trip, a 64-byte line is fetched by four loads microseconds apart -- and again)
@@ -677,6 +678,10 @@ int lds_walk_prepare(const acm_automaton *a, acm_dfa *d)
 	int rc = to_device(&d->d_lds_image, t.image.data(), t.image.size(), &d->device_bytes);
 	if (rc == ACM_OK) rc = to_device(&d->d_lds_out, outp.data(), outp.size(), &d->device_bytes);
 	if (rc == ACM_OK) rc = to_device(&d->d_lds_cid2ref, t.cid2ref.data(), t.cid2ref.size(), &d->device_bytes);
+	std::vector<uint32_t> codes(t.n);
+	for (uint32_t r = 0; r < t.n; r++)
+		codes[r] = t.code_of_ref(r);
+	if (rc == ACM_OK) rc = to_device(&d->d_lds_ref2code, codes.data(), codes.size(), &d->device_bytes);
 	if (rc != ACM_OK)
 		return rc;
 	d->lds_image_bytes = t.image_bytes;
@@ -698,6 +703,7 @@ void lds_walk_release(acm_dfa *d)
 	hipFree(d->d_lds_image);
 	hipFree(d->d_lds_out);
 	hipFree(d->d_lds_cid2ref);
+	hipFree(d->d_lds_ref2code);
 }
 
 // Two launches for up to 16 batches of one size on one stream.  The areas of a batch's workspace are
@@ -734,6 +740,7 @@ int lds_walk_enqueue(const acm_dfa *d, const LdsJob *jobs, uint32_t count, hipSt
 		b.pat_plane = in->d_pat_plane;
 		b.off_plane = in->d_off_plane;
 		b.init_code = d->lds_ref2code[(size_t)in->init_state];
+		b.init_ptr = jobs[i].init_ptr;
 		b.drop_before = (uint32_t)in->halo;
 		b.off_shift = (int32_t)in->offset_shift;
 		b.plane_capacity = (uint32_t)(in->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : in->plane_capacity);

@@ -11,6 +11,7 @@
 // point, every rank straight to the root over its own xGMI link.  RCCL is
 // loaded on first use (dlopen): a single-GPU host never touches it.
 #include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
 
 #include <cstring>
 #include <mutex>
@@ -70,6 +71,7 @@ struct Rccl {
 	int (*group_end)(void) = nullptr;
 	int (*send)(const void *, size_t, int, int, void *, void *) = nullptr;
 	int (*recv)(void *, size_t, int, int, void *, void *) = nullptr;
+	int (*all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
 	const char *(*error_string)(int) = nullptr;
 	bool ok = false;
 };
@@ -88,6 +90,7 @@ Rccl &rccl()
 		r.group_end = (int (*)(void))dlsym(h, "ncclGroupEnd");
 		r.send = (int (*)(const void *, size_t, int, int, void *, void *))dlsym(h, "ncclSend");
 		r.recv = (int (*)(void *, size_t, int, int, void *, void *))dlsym(h, "ncclRecv");
+		r.all_gather = (int (*)(const void *, void *, size_t, int, void *, void *))dlsym(h, "ncclAllGather");
 		r.error_string = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
 		r.ok = r.group_start && r.group_end && r.send && r.recv;
 	});
@@ -127,6 +130,57 @@ extern "C" int acm_gather_planes(void *nccl_comm, int rank, int world, int root,
 			if (rc == ACM_OK)
 				rc = check(r.recv(d_all_off + (size_t)peer * plane_capacity, plane_capacity, kNcclInt32, peer, nccl_comm,
 				    stream), "ncclRecv");
+		}
+	const int end = check(r.group_end(), "ncclGroupEnd");
+	return rc != ACM_OK ? rc : end;
+}
+
+// The gather as SURVEY 8(e) words it: the record counts first (an all-gather of one cell per rank: the
+// header cell of the pattern plane), then sends and receives sized by them -- count + 2 cells of each
+// plane (header, records, trailer) instead of plane_capacity.  The counts live on the device, so the
+// call waits on `stream` once, for 4 * world bytes, between the two steps; a rank whose planes
+// overflowed (count > plane_capacity - 2) sends plane_capacity cells and acm_merge_planes reports it.
+// d_counts: int32[world] scratch on every rank.  counts_out (host, may be null): what each rank sent.
+extern "C" int acm_gather_planes_sized(void *nccl_comm, int rank, int world, int root, const int32_t *d_pat_plane,
+    const int32_t *d_off_plane, size_t plane_capacity, int32_t *d_all_pat, int32_t *d_all_off, int32_t *d_counts,
+    int32_t *counts_out, void *stream)
+{
+	if (!nccl_comm || world <= 0 || world > 4096 || rank < 0 || rank >= world || root < 0 || root >= world || !d_pat_plane ||
+	    !d_off_plane || !d_counts || plane_capacity < 2 || (rank == root && (!d_all_pat || !d_all_off)))
+		return acm::fail(ACM_ERR_ARG, "acm_gather_planes_sized: bad arguments");
+	Rccl &r = rccl();
+	if (!r.ok || !r.all_gather)
+		return acm::fail(ACM_ERR_NODEV, "acm_gather_planes_sized: librccl.so could not be loaded");
+	auto check = [&](int rc, const char *what) -> int {
+		if (rc == 0)
+			return ACM_OK;
+		return acm::fail(ACM_ERR_HIP, "acm_gather_planes_sized: %s: %s", what, r.error_string ? r.error_string(rc) : "RCCL error");
+	};
+	int rc = check(r.all_gather(d_pat_plane, d_counts, 1, kNcclInt32, nccl_comm, stream), "ncclAllGather");
+	if (rc != ACM_OK)
+		return rc;
+	int32_t counts[4096];
+	ACM_HIP_TRY(hipMemcpyAsync(counts, d_counts, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	ACM_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	auto cells_of = [&](int32_t m) -> size_t {
+		const size_t want = (size_t)(m < 0 ? 0 : m) + 2;
+		return want < plane_capacity ? want : plane_capacity;
+	};
+	if (counts_out)
+		memcpy(counts_out, counts, (size_t)world * sizeof(int32_t));
+	rc = check(r.group_start(), "ncclGroupStart");
+	if (rc != ACM_OK)
+		return rc;
+	const size_t mine = cells_of(counts[rank]);
+	rc = check(r.send(d_pat_plane, mine, kNcclInt32, root, nccl_comm, stream), "ncclSend");
+	if (rc == ACM_OK)
+		rc = check(r.send(d_off_plane, mine, kNcclInt32, root, nccl_comm, stream), "ncclSend");
+	if (rank == root)
+		for (int peer = 0; peer < world && rc == ACM_OK; peer++) {
+			const size_t n = cells_of(counts[peer]);
+			rc = check(r.recv(d_all_pat + (size_t)peer * plane_capacity, n, kNcclInt32, peer, nccl_comm, stream), "ncclRecv");
+			if (rc == ACM_OK)
+				rc = check(r.recv(d_all_off + (size_t)peer * plane_capacity, n, kNcclInt32, peer, nccl_comm, stream), "ncclRecv");
 		}
 	const int end = check(r.group_end(), "ncclGroupEnd");
 	return rc != ACM_OK ? rc : end;

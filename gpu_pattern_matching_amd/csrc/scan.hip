@@ -96,6 +96,7 @@ struct ScanArgs {
 	uint32_t L;             // max pattern length
 	uint32_t q;             // look-back chains
 	uint32_t init_state;    // dev numbering
+	const uint32_t *init_ptr;   // not null: the state to start in is THERE (handed over on the device, k_carry_init), init_state is not
 	uint32_t drop_before;   // records ending before this offset are context (halo), not output
 	int32_t off_shift;      // added to every reported offset
 	// workspace
@@ -118,6 +119,12 @@ struct ScanArgs {
 	uint32_t plane_capacity;
 	uint32_t fold_blocks;      // > 0: off[] holds the raw totals of this many blocks; the scatter adds them up itself
 };
+
+// the state the text starts in (wave-uniform: one scalar load where it was handed over on the device)
+__device__ __forceinline__ uint32_t init_of(const ScanArgs &a)
+{
+	return a.init_ptr ? *a.init_ptr : a.init_state;
+}
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
 {
@@ -235,7 +242,7 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs &a, const uint16_t 
 			if (c > 0)
 				pe = prev_slot_last;
 			else if (chain[c] == 0)
-				pe = a.init_state;
+				pe = init_of(a);
 			else
 				known = false;   // previous chain belongs to another wave
 		}
@@ -311,7 +318,7 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 		base[c] = chain[c] << a.logS;
 		len[c] = GUARD ? (base[c] >= a.n ? 0u : min(a.S, a.n - base[c])) : a.S;
 		lead[c] = min(hb, base[c]);
-		st[c] = (HALO && base[c] <= hb) ? a.init_state : 0u;
+		st[c] = (HALO && base[c] <= hb) ? init_of(a) : 0u;
 		cnt[c] = 0;
 		first[c] = kNoFirst;
 		fb[c] = 0;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(kBlock2) void k_probe(ScanArgs a)
 	if (a.probe[c] != kProbeTodo)
 		return;
 	Deep d;
-	d.s = c == 0 ? a.init_state : a.end_state[c - 1];
+	d.s = c == 0 ? init_of(a) : a.end_state[c - 1];
 	d.depth = 0;
 	d.run = 0;
 	const uint32_t base = c << a.logS;
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 		for (uint32_t c = first; c + 1 < j; c++)            // chains first .. j-2 must have merged
 			window_ok &= (a.probe[c] & 1u) != 0;
 		const uint32_t pj = a.probe[j];
-		const uint32_t assumed = j == 0 ? a.init_state : a.end_state[j - 1];
+		const uint32_t assumed = j == 0 ? init_of(a) : a.end_state[j - 1];
 		// q == 1 (S >= L): the window is empty and e[j-1] is already the true state
 		uint32_t state = (j == 0 || first == j) ? assumed : a.wend[j - 1];
 		if (window_ok && state == assumed && !(pj & 2u)) {
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 			if (!window_ok) {
 				// ---- general look-back: true state at the start of chain j ----
 				uint32_t c = first;
-				state = j < a.q ? a.init_state : a.end_state[j - a.q];
+				state = j < a.q ? init_of(a) : a.end_state[j - a.q];
 				ChainText txt(a, first << a.logS);
 				while (c < j) {
 					if (m == 0 && state == 0) {  // root: merged with chain c's own walk
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(kBlock2) void k_resolve(ScanArgs a)
 						c++;
 						continue;
 					}
-					if (m == 0 && state == (c == 0 ? a.init_state : a.end_state[c - 1])) {
+					if (m == 0 && state == (c == 0 ? init_of(a) : a.end_state[c - 1])) {
 						state = a.wend[c];       // exactly the walk the probe of chain c did
 						c++;
 						continue;
@@ -800,12 +807,32 @@ __global__ __launch_bounds__(kBlock2) void k_scatter_all(ScanArgs a)
 	}
 }
 
+// A scan that continues another on the device (acm_scan_batch.d_init_plane): the final state of that scan is in the
+// trailer cell of its pattern plane, behind the header cell that says where (compactarray.cl:49-55 layout;
+// the reference hands it from round to round through the host, databuf.c:622).  One thread translates it
+// into this device's numberings and leaves it in the workspace, where the kernels of the scan look for it.
+__global__ void k_carry_init(const int32_t *plane, uint32_t capacity, const uint32_t *ref2dev, const uint32_t *ref2code,
+    uint32_t states, uint32_t *dev_out, uint32_t *code_out)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0)
+		return;
+	const int32_t m = plane[0];
+	uint32_t tail = (uint32_t)(m < 0 ? 0 : m) + 1;
+	if (tail > capacity - 1)
+		tail = capacity - 1;
+	uint32_t ref = (uint32_t)plane[tail];
+	if (ref >= states)
+		ref = 0;   // (not a state: cannot happen with planes of this library)
+	*dev_out = ref2dev[ref];
+	*code_out = ref2code ? ref2code[ref] : 0u;
+}
+
 // empty text: header and trailer only
 __global__ void k_finalize_empty(ScanArgs a)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0)
 		return;
-	const int32_t last_ref = (int32_t)a.dev2ref[a.init_state];
+	const int32_t last_ref = (int32_t)a.dev2ref[init_of(a)];
 	a.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;
 	a.pat_plane[0] = 0;
 	a.off_plane[0] = 0;
@@ -1030,7 +1057,7 @@ bool lds_path(const acm_dfa *d, bool sparse, size_t n) { return !sparse && d->ld
 // that wait for nothing and are not timed: one group for the sparse kernels
 bool groupable(const acm_dfa *d, const acm_scan_batch &b)
 {
-	return !d->profile && !b.wait_before_walk && !b.record_after_walk && b.n > 0;
+	return !d->profile && !b.wait_before_walk && !b.record_after_walk && !b.d_init_plane && b.n > 0;
 }
 bool joins(const acm_scan_batch *const *group, uint32_t m, const acm_scan_batch &b)
 {
@@ -1191,6 +1218,8 @@ acm_dfa::GraphKey graph_key(const acm_dfa *d, const acm_scan_batch *b, bool spar
 	k.off_plane = b->d_off_plane;
 	k.plane_capacity = b->plane_capacity;
 	k.report = b->report;
+	k.init_plane = b->d_init_plane;
+	k.init_plane_capacity = b->init_plane_capacity;
 	k.mode = sparse ? ACM_SCAN_MODE_SPARSE : ACM_SCAN_MODE_CHAIN;
 	k.chain_bytes = d->chain_bytes;
 	k.chains_per_lane = d->chains_per_lane;
@@ -1335,6 +1364,8 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 	if (halo > n || offset_shift < INT32_MIN || offset_shift > INT32_MAX ||
 	    (long)n + offset_shift > (long)INT32_MAX)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_shard_async: halo/offset_shift out of range");
+	if (batch->d_init_plane && batch->init_plane_capacity < 2)
+		return acm::fail(ACM_ERR_ARG, "acm_scan_batch_async: d_init_plane needs the capacity its scan was given");
 	if (init_state < 0 || (uint64_t)init_state >= d->num_states)
 		return acm::fail(ACM_ERR_ARG, "acm_scan_async: init_state %ld is not a state", init_state);
 	if (plane_capacity > 0xFFFFFFFFul)
@@ -1424,11 +1455,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 	a.off_plane = d_off_plane;
 	a.plane_capacity = (uint32_t)plane_capacity;
 
-	if (a.n_chains == 0) {
-		hipLaunchKernelGGL(k_finalize_empty, dim3(1), dim3(64), 0, s, a);
-		ACM_HIP_TRY(hipGetLastError());
-		return ACM_OK;
-	}
+	const bool empty = a.n_chains == 0;   // (header and trailer only: below, once the state to start in is known)
 
 	hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
 	const bool profile = !defer && (d->profile || batch->profile);   // (a deferred batch is timed with its group)
@@ -1448,9 +1475,34 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 	if (profile)
 		ACM_HIP_TRY(hipEventRecord(ev[0], s));
 	int rc;
+	const uint32_t *init_dev_ptr = nullptr, *init_code_ptr = nullptr;
+	if (batch->d_init_plane) {   // the state to start in comes from another scan's planes, on the device
+		if (defer)
+			return acm::fail(ACM_ERR_ARG, "acm_scan_batches_async: a batch with d_init_plane cannot join a launch group");
+		hipLaunchKernelGGL(k_carry_init, dim3(1), dim3(64), 0, s, batch->d_init_plane,
+		    (uint32_t)std::min<size_t>(batch->init_plane_capacity, 0xFFFFFFFFul), (const uint32_t *)d->d_ref2dev,
+		    (const uint32_t *)(d->lds_ok ? d->d_lds_ref2code : nullptr), d->num_states, a.misc + 4, a.misc + 5);
+		ACM_HIP_TRY(hipGetLastError());
+		init_dev_ptr = a.misc + 4;
+		init_code_ptr = a.misc + 5;
+		a.init_ptr = init_dev_ptr;
+	}
+	if (empty) {
+		hipLaunchKernelGGL(k_finalize_empty, dim3(1), dim3(64), 0, s, a);
+		ACM_HIP_TRY(hipGetLastError());
+		if (profile) {
+			for (int k = 1; k < 4; k++)
+				ACM_HIP_TRY(hipEventRecord(ev[k], s));
+			std::lock_guard<std::mutex> lock(d->profile_mutex);
+			for (auto e : ev)
+				d->profile_events.push_back((void *)e);
+		}
+		return ACM_OK;
+	}
 	if (sparse && defer) {
 		defer->sieve.batch = batch;
 		defer->sieve.init_dev = a.init_state;
+		defer->sieve.init_ptr = nullptr;
 		defer->sieve.sparse_ws = ws + l.sparse;
 		defer->sieve.path_marker = a.misc + 2;
 		return ACM_OK;
@@ -1462,6 +1514,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 		job.cnt = (uint8_t *)(ws + l.cnt);
 		job.tile_total = (uint32_t *)(ws + l.off);
 		job.misc = a.misc;
+		job.init_ptr = init_code_ptr;
 		size_t stage_words, cnt_bytes, tile_words;
 		acm::lds_walk_needs(d, n, &stage_words, &cnt_bytes, &tile_words);
 		if (stage_words * 4 > l.stage2 - l.stage1 || cnt_bytes > l.off - l.cnt || tile_words * 4 > l.wave_cnt1 - l.off)
@@ -1483,7 +1536,7 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 		return ACM_OK;
 	}
 	if (sparse) {   // three kernels of its own; it always produces the planes
-		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, ws + l.sparse, a.misc + 2, s, ev[1], ev[2]);
+		rc = acm::sparse_scan_enqueue(d, batch, a.init_state, init_dev_ptr, ws + l.sparse, a.misc + 2, s, ev[1], ev[2]);
 		if (rc != ACM_OK)
 			return rc;
 		if (batch->record_after_walk)

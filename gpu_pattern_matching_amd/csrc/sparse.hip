@@ -136,6 +136,7 @@ struct SieveArgs {
 	const uint8_t *text;
 	uint32_t n, n_pad;
 	uint32_t init_state, drop_before;
+	const uint32_t *init_ptr;     // not null: the state to start in is there (handed over on the device), init_state is not
 	int32_t off_shift;
 	// geometry
 	uint32_t tile_bytes, ntiles, cap, nrows;   // nrows: static rows = blocks of eight tiles + 1 (the walker's)
@@ -174,6 +175,7 @@ struct SieveBatch {
 	uint32_t init_state, drop_before;
 	int32_t off_shift;
 	uint32_t plane_capacity, report_state;
+	const uint32_t *init_ptr;
 };
 struct SieveGroup {
 	SieveArgs common;         // everything but the fields of SieveBatch and the workspace pointers
@@ -188,6 +190,7 @@ __device__ __forceinline__ SieveArgs batch_view(const SieveGroup &g, uint32_t bi
 	a.text = b.text;
 	a.text16 = (const uint4 *)b.text;
 	a.init_state = b.init_state;
+	a.init_ptr = b.init_ptr;
 	a.drop_before = b.drop_before;
 	a.off_shift = b.off_shift;
 	a.report_state = b.report_state;
@@ -696,7 +699,7 @@ __device__ void side_walks(const SieveArgs &a)
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = t.samples = 0;
 	t.room = a.cap;
-	uint32_t state = a.init_state, x = 0;   // x: next byte to consume
+	uint32_t state = a.init_ptr ? *a.init_ptr : a.init_state, x = 0;   // x: next byte to consume
 	uint32_t run = 0;                        // known unary, non-final path ahead of 'state'
 	while (state != 0) {
 		if (x >= a.n) {
@@ -1602,6 +1605,7 @@ void fill_batch(const SieveJob &job, SieveBatch &b)
 	b.off_plane = in->d_off_plane;
 	b.path_marker = job.path_marker;
 	b.init_state = job.init_dev;
+	b.init_ptr = job.init_ptr;
 	b.drop_before = (uint32_t)in->halo;
 	b.off_shift = (int32_t)in->offset_shift;
 	b.plane_capacity = (uint32_t)(in->plane_capacity > 0xFFFFFFFFul ? 0xFFFFFFFFul : in->plane_capacity);
@@ -1765,12 +1769,13 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	return ACM_OK;
 }
 
-int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, void *sparse_ws,
+int sparse_scan_enqueue(const acm_dfa *d, const acm_scan_batch *b, uint32_t init_dev, const uint32_t *init_ptr, void *sparse_ws,
     uint32_t *path_marker, hipStream_t s, hipEvent_t after_sieve, hipEvent_t after_emit)
 {
 	SieveJob job;
 	job.batch = b;
 	job.init_dev = init_dev;
+	job.init_ptr = init_ptr;
 	job.sparse_ws = sparse_ws;
 	job.path_marker = path_marker;
 	return sparse_group_enqueue(d, &job, 1, s, after_sieve, after_emit);

@@ -212,6 +212,15 @@ typedef struct acm_scan_batch {
 	int profile;			/* non-zero: time this batch's kernels with
 					 * events as acm_scan_profile_enable does
 					 * for all (acm_scan_profile_read collects) */
+	/* The state to start in, handed over on the device: the pattern plane of
+	 * the scan this one continues (its trailer cell, found behind its header
+	 * cell, holds that scan's final state: databuf.c:622, ahomatch.cl:42-43)
+	 * and the capacity that plane was scanned with.  NULL: init_state above.
+	 * The scan it names must be in front of this one on the same stream, or
+	 * complete.  No host read between consecutive buffers of a worker; such a
+	 * batch has its launches to itself (it does not join a launch group). */
+	const int32_t *d_init_plane;
+	size_t init_plane_capacity;
 } acm_scan_batch;
 
 /* What the pattern plane of a scan holds per record.
@@ -394,6 +403,20 @@ int acm_gather_planes(void *nccl_comm, int rank, int world, int root,
     const int32_t *d_pat_plane, const int32_t *d_off_plane,
     size_t plane_capacity, int32_t *d_all_pat, int32_t *d_all_off,
     void *stream);
+
+/* The same with sized messages: an all-gather of the ranks' record
+ * counts (the header cells), then count + 2 cells of each plane per rank instead
+ * of plane_capacity -- 7 MB instead of 2 x 8 MB for the sentiment planes.  The
+ * counts are on the device: the call waits on 'stream' once, for 4 * world
+ * bytes, between the two steps.  d_counts: int32[world] device scratch on every
+ * rank; counts_out: host int32[world] or NULL.  A rank whose count exceeds
+ * plane_capacity - 2 sends plane_capacity cells; acm_merge_planes then returns
+ * ACM_ERR_CAPACITY for it (the single-GPU contract reports such an overflow
+ * through the count in the header cell: the merge has no room for the records). */
+int acm_gather_planes_sized(void *nccl_comm, int rank, int world, int root,
+    const int32_t *d_pat_plane, const int32_t *d_off_plane,
+    size_t plane_capacity, int32_t *d_all_pat, int32_t *d_all_off,
+    int32_t *d_counts, int32_t *counts_out, void *stream);
 
 /* Host side of the root, after the gather has been copied back: rank order
  * is position order, so the ranks' records back to back are the text's

@@ -54,8 +54,21 @@ def test_gather_planes_over_rccl(gpu, lib):
         d = DeviceArray.from_numpy(text[plan.load_begin:plan.load_begin + plan.load_bytes])
         m.scan_async(d, plan.load_bytes, halo=plan.halo, offset_shift=plan.offset_shift)
         all_pat, all_off = DeviceArray(cap * 4), DeviceArray(cap * 4)
-        rc = lib.acm_gather_planes(comm, 0, 1, 0, m.pat_plane.ptr, m.off_plane.ptr, cap, all_pat.ptr, all_off.ptr, m.stream)
-        assert rc == 0, lib.acm_last_error()
+        if rank == 0:      # the fixed-capacity gather ...
+            rc = lib.acm_gather_planes(comm, 0, 1, 0, m.pat_plane.ptr, m.off_plane.ptr, cap, all_pat.ptr, all_off.ptr, m.stream)
+            assert rc == 0, lib.acm_last_error()
+        else:              # ... and the one that gathers the record counts first and sends count + 2 cells
+            all_pat.fill(0xEE, stream=m.stream)
+            all_off.fill(0xEE, stream=m.stream)
+            d_counts = DeviceArray(64)
+            counts = (C.c_int32 * 1)()
+            rc = lib.acm_gather_planes_sized(comm, 0, 1, 0, m.pat_plane.ptr, m.off_plane.ptr, cap, all_pat.ptr, all_off.ptr,
+                                             d_counts.ptr, counts, m.stream)
+            assert rc == 0, lib.acm_last_error()
+            got = all_pat.to_numpy(np.int32, cap, stream=m.stream)
+            assert counts[0] == got[0] and 0 < counts[0] < cap - 2
+            assert (got[counts[0] + 2:] == np.int32(-286331154)).all()     # 0xEEEEEEEE: nothing behind the trailer cell was sent
+            d_counts.free()
         host_pat[rank] = all_pat.to_numpy(np.int32, cap, stream=m.stream)
         host_off[rank] = all_off.to_numpy(np.int32, cap, stream=m.stream)
         for b in (d, all_pat, all_off):
