@@ -176,8 +176,10 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         # groups keep the bulk kernel busy; a fourth adds 3-5 % on long blocks (4.3-4.5 against 4.1-4.3 TB/s),
         # nothing on 20-step blocks, and costs 50-step blocks 4 % -- and the bulk kernels of the streams queue
         # behind each other, so every launch then takes a third longer from dispatch to end.  The chain
-        # pipeline's walk kernel fills the device by itself.
-        workers = 3
+        # pipeline's LDS-resident walk fills every CU by itself (all of its LDS): two streams, one's walk kernel and
+        # the other's scatter kernel in its shadow (a third only adds scatter workgroups that keep walk
+        # workgroups waiting for a CU: 940 against 1060 GB/s).
+        workers = 2 if matcher.lds_resident() and args.mode != "sparse" and not matcher.sparse_eligible() else 3
 
     # ---- texts.  Logical text i = world shards of 32 MiB (weak) or one 32 MiB text (strong); rank r
     #      loads its range plus the halo in front of it -------------------------------------------
@@ -238,6 +240,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     # consecutive steps on one stream)
     groups_apply = matcher.group_capable()
     Geff = G if (args.issue != "main" and groups_apply) else 1
+    if args.deal != "groups":
+        # a block shorter than W full groups: every worker an equal share (20 steps: 7 + 7 + 6 instead of 16 + 4,
+        # +3 %; the chain pipeline's walk kernels run one after the other whatever the stream, each with the
+        # scatter of the group in front in its shadow: 10 + 10 steps overlap, 16 + 4 hardly, +2 %)
+        Geff = max(1, min(Geff, -(-K // W)))
 
     # The steps are dealt to the workers a launch group at a time: steps 0 .. Geff-1 to worker 0, the next
     # Geff to worker 1, ...  (a short block then ends with ONE short group, not with one per worker)
@@ -645,6 +652,8 @@ def main():
     ap.add_argument("--chain-bytes", type=int, default=0, help="chain pipeline: bytes per chain (0: automatic)")
     ap.add_argument("--group", type=int, default=16,
                     help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..16")
+    ap.add_argument("--deal", default="even", choices=["groups", "even"],
+                    help="a block shorter than workers x group steps: full groups first (groups) or equal shares (even)")
     ap.add_argument("--issue", default="native", choices=["native", "threads", "main"],
                     help="who enqueues the steps of a block: one acm_scan_batches_async call from the main thread, one "
                          "host thread per worker (each with one such call), or the main thread step by step")

@@ -34,7 +34,7 @@ namespace acm {
 constexpr uint32_t kCompactMaxStates = 16384;
 constexpr uint32_t kCompactSideBase = 0xC000;
 constexpr uint32_t kCompactNoClass = 0xFF;
-constexpr uint32_t kCompactLdsBytes = 160 * 1024 - 512;   // what the image may take of a CU's LDS
+constexpr uint32_t kCompactLdsBytes = 160 * 1024 - 2048;   // what the image may take of a CU's LDS (the rest: the few words of a scatter workgroup running next to the walk)
 
 struct CompactTables {
 	bool ok = false;

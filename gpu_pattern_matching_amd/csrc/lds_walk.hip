@@ -34,7 +34,11 @@ namespace {
 
 constexpr int kWalkBlock = 1024;               // 16 waves: the whole CU (the image takes all of its LDS)
 constexpr int kWalkWaves = kWalkBlock / 64;
-constexpr int kScatterBlock = 1024;             // chains per scatter workgroup (every workgroup adds up the tile totals in front of it: fewer, larger ones)
+// chains per scatter workgroup.  Every workgroup adds up the tile totals in front of it, which speaks for few, large
+// ones; but 512 threads of 64 registers are what fits a CU next to a walk workgroup of 16 waves x 96 registers (and
+// the few bytes of LDS the image leaves), so that the scatter of one stream's batches runs in the shadow of the
+// next stream's walk.
+constexpr int kScatterBlockDefault = 0;   // 0: k_lds_scatter_wide
 constexpr uint32_t kChainBytes = 64, kLogChain = 6;
 constexpr uint32_t kMaxHaloGroups = 2;         // hb <= 32: patterns of up to 33 bytes
 constexpr uint32_t kGroups = kChainBytes / 16 + kMaxHaloGroups;   // 16-byte groups a lane holds per chain
@@ -162,7 +166,7 @@ __device__ __forceinline__ uint32_t next_code(const uint8_t *lds, uint32_t off_r
 // looks at is picked by v_perm from the dword of the step and the one in front of it, selector nd + r.
 // A lane can be four bytes behind; one that would fall further is left to the caller (slowA / slowB:
 // once in a few thousand chains).  The drains at the end of the halo and of the chain bring everybody
-// level again.  v120..v123 hold the two records; the two chains' LDS reads are interleaved and waited for
+// level again.  v84..v87 hold the two records (fixed registers: the halves of a 64-bit asm operand cannot be named; low ones, so that they do not push the kernel's register count up); the two chains' LDS reads are interleaved and waited for
 // by count.  EMIT: a final state entered (by a lane that did not defer) is stored as
 // {code, step - bytes behind} in the lane's list, 256 bytes further for every record.
 template <int R, bool EMIT>
@@ -179,37 +183,37 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 	"v_and_b32 %[t1], 0x7ffe, %[inA]\n\t"                                                                       \
 	"v_lshl_add_u32 %[t1], %[t1], 2, %[orec]\n\t"                                                               \
 	"ds_read_u8 %[clsA], %[t0]\n\t"                                                                             \
-	"ds_read_b64 v[120:121], %[t1]\n\t"                                                                         \
+	"ds_read_b64 v[84:85], %[t1]\n\t"                                                                         \
 	"v_add_u32 %[t2], " sel ", %[ndB]\n\t"                                                                      \
 	"v_perm_b32 %[t2], %[hiB], %[loB], %[t2]\n\t"                                                               \
 	"v_and_b32 %[t3], 0x7ffe, %[inB]\n\t"                                                                       \
 	"v_lshl_add_u32 %[t3], %[t3], 2, %[orec]\n\t"                                                               \
 	"ds_read_u8 %[clsB], %[t2]\n\t"                                                                             \
-	"ds_read_b64 v[122:123], %[t3]\n\t"                                                                         \
+	"ds_read_b64 v[86:87], %[t3]\n\t"                                                                         \
 	"s_waitcnt lgkmcnt(2)\n\t"                                                                                  \
-	"v_add_u32_sdwa %[t0], %[clsA], v121 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+	"v_add_u32_sdwa %[t0], %[clsA], v85 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
 	"v_lshlrev_b32 %[t0], 1, %[t0]\n\t"                                                                         \
 	"ds_read_u16 %[t0], %[t0]\n\t"                                                                              \
-	"v_cmp_eq_u32_sdwa %[m1A], v120, %[clsA] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
-	"v_cmp_eq_u32_sdwa %[m2A], v120, %[clsA] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
-	"v_cmp_le_u32_e64 %[moreA], %[c0], v121\n\t"                                                                \
+	"v_cmp_eq_u32_sdwa %[m1A], v84, %[clsA] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
+	"v_cmp_eq_u32_sdwa %[m2A], v84, %[clsA] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
+	"v_cmp_le_u32_e64 %[moreA], %[c0], v85\n\t"                                                                \
 	"s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
-	"v_add_u32_sdwa %[t2], %[clsB], v123 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+	"v_add_u32_sdwa %[t2], %[clsB], v87 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
 	"v_lshlrev_b32 %[t2], 1, %[t2]\n\t"                                                                         \
 	"ds_read_u16 %[t2], %[t2]\n\t"                                                                              \
-	"v_cmp_eq_u32_sdwa %[m1B], v122, %[clsB] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
-	"v_cmp_eq_u32_sdwa %[m2B], v122, %[clsB] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
-	"v_cmp_le_u32_e64 %[moreB], %[c0], v123\n\t"                                                                \
+	"v_cmp_eq_u32_sdwa %[m1B], v86, %[clsB] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
+	"v_cmp_eq_u32_sdwa %[m2B], v86, %[clsB] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
+	"v_cmp_le_u32_e64 %[moreB], %[c0], v87\n\t"                                                                \
 	"s_mov_b64 %[slowA], 0\n\t"                                                                                 \
 	"s_mov_b64 %[slowB], 0\n\t"                                                                                 \
 	"s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
-	"v_cndmask_b32_e64 %[eA], %[t0], v121, %[m2A]\n\t"                                                          \
-	"v_cndmask_b32_e64 %[eA], %[eA], v120, %[m1A]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eA], %[t0], v85, %[m2A]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eA], %[eA], v84, %[m1A]\n\t"                                                          \
 	"s_or_b64 %[m1A], %[m1A], %[m2A]\n\t"                                                                       \
 	"s_andn2_b64 %[moreA], %[moreA], %[m1A]\n\t"                                                                \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
-	"v_cndmask_b32_e64 %[eB], %[t2], v123, %[m2B]\n\t"                                                          \
-	"v_cndmask_b32_e64 %[eB], %[eB], v122, %[m1B]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eB], %[t2], v87, %[m2B]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eB], %[eB], v86, %[m1B]\n\t"                                                          \
 	"s_or_b64 %[m1B], %[m1B], %[m2B]\n\t"                                                                       \
 	"s_andn2_b64 %[moreB], %[moreB], %[m1B]\n\t"                                                                \
 	"s_or_b64 %[sv], %[moreA], %[moreB]\n\t"                                                                    \
@@ -220,8 +224,8 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 	"s_and_b64 %[slowB], %[slowB], %[moreB]\n\t"                                                                \
 	"s_andn2_b64 %[m1A], %[moreA], %[slowA]\n\t"                                                                \
 	"s_andn2_b64 %[m1B], %[moreB], %[slowB]\n\t"                                                                \
-	"v_lshrrev_b32 %[t1], 15, v121\n\t"                                                                         \
-	"v_lshrrev_b32 %[t3], 15, v123\n\t"                                                                         \
+	"v_lshrrev_b32 %[t1], 15, v85\n\t"                                                                         \
+	"v_lshrrev_b32 %[t3], 15, v87\n\t"                                                                         \
 	"v_cndmask_b32_e64 %[eA], %[eA], %[t1], %[m1A]\n\t"                                                         \
 	"v_cndmask_b32_e64 %[eB], %[eB], %[t3], %[m1B]\n\t"                                                         \
 	"v_subb_co_u32_e64 %[ndA], %[m2A], %[ndA], 0, %[m1A]\n\t"                                                   \
@@ -251,7 +255,7 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 	  [moreB] "=&s"(moreB), [slowA] "=&s"(slowA), [slowB] "=&s"(slowB), [sv] "=&s"(sv)                          \
 	: [hiA] "v"(hiA), [loA] "v"(loA), [hiB] "v"(hiB), [loB] "v"(loB), [inA] "v"(inA), [inB] "v"(inB),            \
 	  [orec] "s"(off_rec), [c0] "s"(c0), [ffff] "s"(ffff), [sc] "s"(stepconst), [base] "s"(stage)                \
-	: "v120", "v121", "v122", "v123", "memory", "scc"
+	: "v84", "v85", "v86", "v87", "memory", "scc"
 	// selector of v_perm: byte nd + r of {hi, lo} (lo = bytes 0..3), the other three bytes of the result zero
 	if (EMIT) {
 		if (R == 0) asm volatile(ACM_WALK("0x0c0c0c00") ACM_EMIT ACM_OPS);
@@ -319,6 +323,8 @@ __device__ __forceinline__ void drain(const uint8_t *lds, uint32_t off_rec, uint
 }
 
 // A whole tile (no end of the text, no shard halo inside it) of two chains per lane, the written-out step.
+// NG: 16-byte groups a lane holds per chain (5: a halo of one group, 6: of two).
+template <int NG>
 __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch &b, const uint8_t *lds, uint32_t wt, uint32_t lane)
 {
 	constexpr int C = 2;
@@ -349,7 +355,8 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		p2[c] = text16[g0 + 2];
 		p3[c] = text16[g0 + 3];
 		p4[c] = groups > 4 ? text16[g0 + 4] : make_uint4(0, 0, 0, 0);
-		p5[c] = groups > 5 ? text16[g0 + 5] : make_uint4(0, 0, 0, 0);
+		if constexpr (NG > 5)
+			p5[c] = groups > 5 ? text16[g0 + 5] : make_uint4(0, 0, 0, 0);
 	}
 	static_assert(kMaxHaloGroups == 2, "the first two groups may be halo");
 #define ACM_PICK(gi)                                                                     \
@@ -361,7 +368,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 			else if (gu == 1) w[c] = p1[c];                                  \
 			else if (gu == 2) w[c] = p2[c];                                  \
 			else if (gu == 3) w[c] = p3[c];                                  \
-			else if (gu == 4) w[c] = p4[c];                                  \
+			else if (NG <= 5 || gu == 4) w[c] = p4[c];                       \
 			else w[c] = p5[c];                                               \
 		}                                                                        \
 	}
@@ -414,7 +421,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		b.tile_total[wt] = total;
 }
 
-template <int C, bool LIVE>
+template <int C, bool LIVE, int NG = 6>
 __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, const uint8_t *lds, uint32_t wt, uint32_t lane)
 {
 	const uint32_t hb = g.hb, off_rec = g.off_rec;
@@ -453,7 +460,8 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 		p2[c] = fetch(2);
 		p3[c] = fetch(3);
 		p4[c] = fetch(4);
-		p5[c] = fetch(5);
+		if constexpr (NG > 5)
+			p5[c] = fetch(5);
 	}
 	const uint32_t hg = hb >> 4;   // groups that are halo
 	// (rolled loops over the groups, a wave-uniform pick of the register set: sixteen steps of C chains
@@ -467,7 +475,7 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 			else if (gu == 1) w[c] = p1[c];                                  \
 			else if (gu == 2) w[c] = p2[c];                                  \
 			else if (gu == 3) w[c] = p3[c];                                  \
-			else if (gu == 4) w[c] = p4[c];                                  \
+			else if (NG <= 5 || gu == 4) w[c] = p4[c];                       \
 			else w[c] = p5[c];                                               \
 		}                                                                        \
 	}
@@ -513,7 +521,7 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 		b.tile_total[wt] = total;
 }
 
-template <int C, bool ASM>
+template <int C, bool ASM, int NG>
 __global__ __launch_bounds__(kWalkBlock) void k_lds_walk(LdsGroup g)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -540,20 +548,20 @@ __global__ __launch_bounds__(kWalkBlock) void k_lds_walk(LdsGroup g)
 		const bool whole = first + tile_bytes <= g.n && first >= b.drop_before;
 		if constexpr (ASM && C == 2) {
 			if (whole)
-				walk_tile_fast(g, b, lds, wt, lane);   // (copes with the text's first chain itself)
+				walk_tile_fast<NG>(g, b, lds, wt, lane);   // (copes with the text's first chain itself)
 			else
-				walk_tile<C, true>(g, b, lds, wt, lane);
+				walk_tile<C, true, NG>(g, b, lds, wt, lane);
 		} else {
 			if (whole && first >= g.hb)
-				walk_tile<C, false>(g, b, lds, wt, lane);
+				walk_tile<C, false, NG>(g, b, lds, wt, lane);
 			else
-				walk_tile<C, true>(g, b, lds, wt, lane);
+				walk_tile<C, true, NG>(g, b, lds, wt, lane);
 		}
 	}
 }
 
 // Ordered scatter: a workgroup per 1024 chains of one batch.
-template <int C>
+template <int C, int kScatterBlock>
 __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 {
 	__shared__ uint32_t wtot[kScatterBlock / 64];
@@ -639,6 +647,134 @@ __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 	}
 }
 
+// The same, built to run in the SHADOW of another stream's walk kernel, whose workgroup leaves a CU 128
+// registers per lane and SIMD, a few hundred bytes of LDS and a fifth of the issue slots: with two waves per SIMD
+// the levels of dependent loads are what it costs, so a thread takes Q chains (T apart, i.e. four tiles apart)
+// through them together -- counts and tile totals; scan; up to 12 staged records of its chains in one level, their
+// patterns in the next, then the stores -- and a workgroup covers T * Q chains: 256 workgroups per 32 MiB batch.
+template <int C, int T, int Q, bool PRIO>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lds_scatter_wide(LdsGroup g)   // (64 registers: two of its waves per SIMD next to a walk workgroup)
+{
+	constexpr uint32_t W = T / 64, kPer = T * Q, kSlots = 12;
+	static_assert(Q == 4 && T % (C * 64) == 0, "four chains a thread, whole tiles per slab");
+	// (the walk kernel next door is bound by instruction issue and has four waves per SIMD ready at any time: these
+	// waves, which mostly wait for memory, go first when they have something to issue)
+	if (PRIO)
+		__builtin_amdgcn_s_setprio(3);
+	__shared__ uint32_t wtot[Q * W];
+	__shared__ uint32_t part[W], part_all[W];
+	const uint32_t nb = (g.n_chains + kPer - 1) / kPer;
+	const uint32_t bi = blockIdx.x / nb, blk = blockIdx.x - bi * nb;
+	const LdsBatch &b = g.b[bi];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t j0 = blk * kPer + tid;
+	uint32_t c[Q], inc[Q];
+#pragma unroll
+	for (int q = 0; q < Q; q++) {
+		const uint32_t j = j0 + q * T;
+		c[q] = j < g.n_chains ? (uint32_t)b.cnt[j] : 0u;
+	}
+	constexpr uint32_t kTilesPer = kPer / (C * 64);
+	uint32_t mine = 0, all = 0;
+	const uint32_t mine_upto = blk * kTilesPer, upto = blk == 0 ? g.n_tiles : mine_upto;
+	for (uint32_t i = tid; i < upto; i += T) {
+		const uint32_t v = b.tile_total[i];
+		all += v;
+		mine += i < mine_upto ? v : 0u;
+	}
+#pragma unroll
+	for (int q = 0; q < Q; q++)
+		inc[q] = c[q];
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+		for (int q = 0; q < Q; q++) {
+			const uint32_t t = __shfl_up(inc[q], o, 64);
+			if (lane >= (uint32_t)o)
+				inc[q] += t;
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		mine += __shfl_xor(mine, o, 64);
+		all += __shfl_xor(all, o, 64);
+	}
+	if (lane == 63) {
+#pragma unroll
+		for (int q = 0; q < Q; q++)
+			wtot[q * W + wv] = inc[q];
+	}
+	if (lane == 0) {
+		part[wv] = mine;
+		part_all[wv] = all;
+	}
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < W; w++) {
+		before += part[w];
+		total += part_all[w];
+	}
+	// where the records of the thread's chain q go: behind the tiles in front of the workgroup, the slabs in front
+	// of q and the waves in front of this one in slab q
+	uint32_t d[Q];
+	uint32_t run = before;
+#pragma unroll
+	for (int q = 0; q < Q; q++) {
+#pragma unroll
+		for (uint32_t w = 0; w < W; w++) {
+			if (w == wv)
+				d[q] = run;   // (select, not a branch: wv is uniform in the wave)
+			run += wtot[q * W + w];
+		}
+		d[q] += inc[q] - c[q];
+	}
+	const uint32_t cum1 = c[0], cum2 = cum1 + c[1], cum3 = cum2 + c[2], tot = cum3 + c[3];
+	// chain j = (tile * C + slot) * 64 + lane: its list is stage[tile][slot][k][lane]; chain q of the thread is
+	// T chains = T / 64 slots further
+	const uint32_t *list0 = b.stage + (size_t)(j0 >> 6) * (kChainBytes * 64) + lane;
+	constexpr uint32_t kSlab = (T / 64) * (kChainBytes * 64);
+	const int32_t *outp = b.report_state ? (const int32_t *)g.cid2ref : g.out;
+	const uint32_t base0 = j0 << kLogChain;
+	const uint32_t cap = b.plane_capacity;
+	for (uint32_t r0 = 0; __builtin_amdgcn_ballot_w64(r0 < tot); r0 += kSlots) {
+		uint32_t rec[kSlots];
+		int32_t pat[kSlots];
+#pragma unroll
+		for (uint32_t i = 0; i < kSlots; i++) {
+			const uint32_t idx = r0 + i;
+			const uint32_t q = (idx >= cum1) + (idx >= cum2) + (idx >= cum3);
+			const uint32_t k = idx - (q == 0 ? 0u : q == 1 ? cum1 : q == 2 ? cum2 : cum3);
+			rec[i] = idx < tot ? list0[q * kSlab + k * 64] : 0u;
+		}
+#pragma unroll
+		for (uint32_t i = 0; i < kSlots; i++)
+			pat[i] = r0 + i < tot ? outp[(rec[i] & 0x7FFEu) >> 1] : 0;
+#pragma unroll
+		for (uint32_t i = 0; i < kSlots; i++) {
+			const uint32_t idx = r0 + i;
+			const uint32_t q = (idx >= cum1) + (idx >= cum2) + (idx >= cum3);
+			const uint32_t k = idx - (q == 0 ? 0u : q == 1 ? cum1 : q == 2 ? cum2 : cum3);
+			const uint32_t at = (q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : d[3]) + k;
+			if (idx < tot && at + 2 < cap) {
+				b.pat_plane[1 + at] = pat[i];
+				b.off_plane[1 + at] = (int32_t)(base0 + q * (T << kLogChain) + (rec[i] >> 16)) + b.off_shift;
+			}
+		}
+	}
+	if (blk == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
+		const int32_t last_ref = (int32_t)g.cid2ref[(b.misc[0] & 0x7FFEu) >> 1];
+		b.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
+		uint32_t tail = total + 1;
+		if (tail > b.plane_capacity - 1)
+			tail = b.plane_capacity - 1;
+		b.pat_plane[0] = (int32_t)total;
+		b.off_plane[0] = (int32_t)total;
+		b.pat_plane[tail] = last_ref;
+		b.off_plane[tail] = last_ref;
+	}
+}
+
 template <typename T>
 int to_device(T **dptr, const T *src, size_t count, size_t *total)
 {
@@ -691,7 +827,8 @@ int lds_walk_prepare(const acm_automaton *a, acm_dfa *d)
 	d->lds_ref2code.resize(t.n);
 	for (uint32_t r = 0; r < t.n; r++)
 		d->lds_ref2code[r] = (uint16_t)t.code_of_ref(r);
-	const void *kernels[] = { (const void *)k_lds_walk<kChains, true>, (const void *)k_lds_walk<kChains, false> };
+	const void *kernels[] = { (const void *)k_lds_walk<kChains, true, 5>, (const void *)k_lds_walk<kChains, true, 6>,
+		(const void *)k_lds_walk<kChains, false, 6> };
 	for (const void *k : kernels)
 		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.image_bytes));
 	d->lds_ok = true;
@@ -750,17 +887,33 @@ int lds_walk_enqueue(const acm_dfa *d, const LdsJob *jobs, uint32_t count, hipSt
 	uint32_t blocks = (all_tiles + kWalkWaves - 1) / kWalkWaves;
 	if (blocks > (uint32_t)d->num_cus)
 		blocks = (uint32_t)d->num_cus;
-	const uint32_t sblocks = ((g.n_chains + kScatterBlock - 1) / kScatterBlock) * count;
 	static const bool plain = getenv("ACM_LDS_NOASM") != nullptr;   // debugging aid: the compiler's version of the step
+	static const int sblock = getenv("ACM_LDS_SCATTER_BLOCK") ? atoi(getenv("ACM_LDS_SCATTER_BLOCK")) : kScatterBlockDefault;
 	if (plain)
-		hipLaunchKernelGGL((k_lds_walk<C, false>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);
+		hipLaunchKernelGGL((k_lds_walk<C, false, 6>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);
+	else if (g.hb <= 16)
+		hipLaunchKernelGGL((k_lds_walk<C, true, 5>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);   // 96 registers instead of 104
 	else
-		hipLaunchKernelGGL((k_lds_walk<C, true>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);
+		hipLaunchKernelGGL((k_lds_walk<C, true, 6>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);
 	if (after_walk)
 		ACM_HIP_TRY(hipEventRecord(after_walk, s));
 	if (after_walk2)
 		ACM_HIP_TRY(hipEventRecord(after_walk2, s));
-	hipLaunchKernelGGL(k_lds_scatter<C>, dim3(sblocks), dim3(kScatterBlock), 0, s, g);
+	auto sblocks = [&](uint32_t per) { return dim3(((g.n_chains + per - 1) / per) * count); };
+	if (sblock == 0)
+	{
+		static const bool prio = getenv("ACM_LDS_SCATTER_PRIO") ? atoi(getenv("ACM_LDS_SCATTER_PRIO")) != 0 : false;
+		if (prio)
+			hipLaunchKernelGGL((k_lds_scatter_wide<C, 512, 4, true>), sblocks(2048), dim3(512), 0, s, g);
+		else
+			hipLaunchKernelGGL((k_lds_scatter_wide<C, 512, 4, false>), sblocks(2048), dim3(512), 0, s, g);
+	}
+	else if (sblock == 1024)
+		hipLaunchKernelGGL((k_lds_scatter<C, 1024>), sblocks(1024), dim3(1024), 0, s, g);
+	else if (sblock == 256)
+		hipLaunchKernelGGL((k_lds_scatter<C, 256>), sblocks(256), dim3(256), 0, s, g);
+	else
+		hipLaunchKernelGGL((k_lds_scatter<C, 512>), sblocks(512), dim3(512), 0, s, g);
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }
