@@ -151,6 +151,29 @@ class Pool:
         self.go.wait()
 
 
+def rccl_communicator(torch, dist, rank, world, dev):
+    """--gather abi: an RCCL communicator of the caller's own, as a C or Go host of libacmatch.so would make it
+    (ncclGetUniqueId on rank 0, handed round -- here through the process group --, ncclCommInitRank), for
+    acm_gather_planes."""
+    import ctypes as C
+
+    class NcclUniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl = C.CDLL("librccl.so")
+    uid = NcclUniqueId()
+    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
+    dist.broadcast(t, src=0)
+    C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+    if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
+        raise RuntimeError("ncclCommInitRank failed")
+    return comm
+
+
 def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headline):
     """Everything for one workload; returns the record (rank 0) or None."""
     import torch
@@ -268,6 +291,12 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
     planes = torch.zeros((slots, 2, cap), dtype=torch.int32, device=dev)
     gathered = [torch.empty_like(planes) for _ in range(world)] if (world > 1 and rank == 0) else None
     gather_stream = torch.cuda.Stream(device=dev)
+    abi_buf = None
+    if ctx.get("rccl_comm") is not None:
+        if gathered is None and rank == 0:       # (world size 1 rehearsal: the gather still runs, into a scratch copy)
+            gathered = [torch.empty_like(planes)]
+        if rank == 0:
+            abi_buf = [torch.empty(world * planes.numel() // 2, dtype=torch.int32, device=dev) for _ in range(2)]
 
     def timed(k):
         """is step k one of worker 0's whose kernels are timed?  Whole launch groups, every pe-th of them."""
@@ -353,7 +382,26 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
         for s in streams:                               # behind every worker's scans so far
             gather_stream.wait_stream(s)
         with torch.cuda.stream(gather_stream):
-            if ctx["backend"] == "nccl":
+            if ctx.get("rccl_comm") is not None:
+                # --gather abi: the library's own gather on a communicator of its own (include/acmatch.h,
+                # acm_gather_planes: ncclSend/ncclRecv in one group).  The piece's planes go as ONE pair of
+                # "planes" of half its cells each -- the call moves bytes, it does not look at them.
+                half = mine.numel() // 2
+                flat = mine.view(-1)
+                if rank == 0:
+                    allp = abi_buf[0][:world * half]
+                    allo = abi_buf[1][:world * half]
+                rc = matcher.lib.acm_gather_planes(ctx["rccl_comm"], rank, world, 0, flat.data_ptr(), flat.data_ptr() + half * 4,
+                                                   half, allp.data_ptr() if rank == 0 else None,
+                                                   allo.data_ptr() if rank == 0 else None, gather_stream.cuda_stream)
+                if rc:
+                    check(rc, "acm_gather_planes")
+                if rank == 0 and gathered is not None:
+                    for r, g in enumerate(gathered):
+                        gv = g[lo:hi].view(-1)
+                        gv[:half].copy_(allp[r * half:(r + 1) * half])
+                        gv[half:].copy_(allo[r * half:(r + 1) * half])
+            elif ctx["backend"] == "nccl":
                 into = [g[lo:hi] for g in gathered] if gathered is not None else [torch.empty_like(mine)]
                 dist.gather(mine, gather_list=into if rank == 0 else None, dst=0)
             else:                                       # rehearsal on one GPU: through the host
@@ -568,6 +616,8 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "batches_per_launch_group": G if (groups_apply and args.issue != "main") else 1,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
+                "gather": ("acm_gather_planes (own RCCL communicator)" if ctx.get("rccl_comm") is not None
+                           else "torch.distributed gather (RCCL)" if dist.is_initialized() else "none (one rank)"),
             },
             "host_enqueue_us_per_step": round(statistics.median(host_issue) / K * 1e6, 2),
             "matches_per_step": m_total,
@@ -654,6 +704,9 @@ def main():
                     help="batches of one worker that go into one set of kernel launches (acm_scan_set_max_group): 1..16")
     ap.add_argument("--deal", default="even", choices=["groups", "even"],
                     help="a block shorter than workers x group steps: full groups first (groups) or equal shares (even)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "abi"],
+                    help="N > 1: the block's planes go to rank 0 through torch.distributed's gather (RCCL) or through "
+                         "the library's acm_gather_planes on an RCCL communicator of bench.py's own")
     ap.add_argument("--issue", default="native", choices=["native", "threads", "main"],
                     help="who enqueues the steps of a block: one acm_scan_batches_async call from the main thread, one "
                          "host thread per worker (each with one such call), or the main thread step by step")
@@ -703,7 +756,9 @@ def main():
     from gpu_pattern_matching_amd import build
     build.build()          # no-op when libacmatch.so is current; raises if it cannot be built
     ctx = {"rank": rank, "world": world, "local_rank": local_rank, "dev": torch.device("cuda", local_rank),
-           "backend": backend, "args": args}
+           "backend": backend, "args": args, "rccl_comm": None}
+    if args.gather == "abi" and dist.is_initialized() and backend == "nccl":
+        ctx["rccl_comm"] = rccl_communicator(torch, dist, rank, world, ctx["dev"])
 
     head = run_workload(ctx, Workload(args.workload, args.plant), args.steps, args.warmup, args.repeats,
                         max(1, args.texts), args.workers, not args.no_verify, True)

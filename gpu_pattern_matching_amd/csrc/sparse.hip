@@ -99,6 +99,11 @@ constexpr uint32_t kBusyDivisor = 48;      // ... or a flagged sample per this m
                                            // (with helper waves the sparse pipeline keeps up with the chain pipeline's 70..95 us to about 700 k samples
                                            // per 32 MiB: 62 us at 447 k, 91 at 650 k, 106 at 983 k -- tools/real_data_probe.py)
 constexpr int kEmitBlock = 1024;
+#ifdef ACM_SIEVE_CHECK_STAMPS   // debugging aid (with ACM_SIEVE_STAMPS=1 at run time): clock stamps and level counts of the check
+constexpr bool kCheckStamps = true;    // kernel's waves -- compiled in on request only, they cost the kernel registers
+#else
+constexpr bool kCheckStamps = false;
+#endif
 constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // static rows: the carried-state walker + a block of eight tiles each
 // A block whose tiles hold more flagged samples than this (real binaries: the 3-grams of code and tables
 // cluster) is cut into SUB-ROWS of at most this many samples, in position order; the block's own wave
@@ -601,7 +606,7 @@ __device__ __forceinline__ void stage2_round(const SieveArgs &a, Row &t, RowRef 
 			}
 		}
 		if (mode == kKeep) {
-			if (a.stamps) {
+			if (kCheckStamps && a.stamps) {
 				uint32_t lv = h.levels;
 #pragma unroll
 				for (int o = 32; o > 0; o >>= 1)
@@ -1048,16 +1053,22 @@ __device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, ui
 
 // Sub-row j of block blk: its samples [j * kSubRow, (j + 1) * kSubRow) through both stages, its summary
 // under `slot`.  word7: what a static row's summary says about its block's sub-rows.
-template <int W>
-__device__ __forceinline__ void check_subrow(const SieveArgs &a, uint32_t (*q2)[kQ2Cap], uint32_t lane, uint32_t blk, uint32_t j,
-    uint32_t slot, uint32_t word7, const BlockCounts &bc, unsigned long long *stamp)
+// Returns the number of sub-rows the block has beyond its first.  (The counts are loaded in here, not handed in:
+// carried around the caller's loop they cost the kernel thirty registers.)
+// WHOLE: no sub-rows, the block is one row (no helper waves launched: cutting it up would only be bookkeeping).
+template <int W, bool WHOLE>
+__device__ __forceinline__ uint32_t check_subrow(const SieveArgs &a, uint32_t (*q2)[kQ2Cap], uint32_t lane, uint32_t blk, uint32_t j,
+    uint32_t slot, unsigned long long *stamp)
 {
+	BlockCounts bc;
+	load_counts(a, blk, lane, bc);
 	const uint32_t tile0 = blk * kTilesPerChecker;
 	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
 	const uint32_t ns = bc.cum[kTilesPerChecker];
-	const uint32_t lo = j * a.subrow, hi = min(ns, lo + a.subrow);
+	const uint32_t extras = !WHOLE && ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
+	const uint32_t lo = WHOLE ? 0u : j * a.subrow, hi = WHOLE ? ns : min(ns, lo + a.subrow);
 	t.samples = j == 0 ? ns : 0u;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
 	// the block's list region; a sub-row's part of it starts where its first sample lies, plus the room
 	// the sub-rows in front need beyond their spans (set below, once that sample is known)
@@ -1135,12 +1146,13 @@ __device__ __forceinline__ void check_subrow(const SieveArgs &a, uint32_t (*q2)[
 		stage1_round<W>(a, fq, it.x, it.y, act, lane);
 	}
 	if (lane == 0)
-		write_summary(a, t, slot, j == 0 ? word7 : row.lbase);
+		write_summary(a, t, slot, j == 0 ? extras : row.lbase);
 	if (stamp && lane == 0) {
 		stamp[4] = __builtin_amdgcn_s_memrealtime();
 		stamp[5] = ((unsigned long long)dbg_rounds << 32) | dbg_cands;
 		stamp[6] = ((unsigned long long)dbg_levels << 32);
 	}
+	return extras;
 }
 
 // lane 0 asks, every lane gets the answer
@@ -1152,7 +1164,10 @@ __device__ __forceinline__ void check_subrow(const SieveArgs &a, uint32_t (*q2)[
 		return (uint32_t)__builtin_amdgcn_readfirstlane((int)v_);  \
 	}())
 
-template <int W>
+// HELPED: helper waves were launched (the last batches were sample-heavy).  Without them (the common case) every
+// block is one row and the kernel is a straight line: the loop of the helped kind costs 40 registers, and next to
+// two bulk workgroups a SIMD has 128 left for the checks of the other streams' batches.
+template <int W, bool HELPED>
 __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint32_t helpers)
 {
 	__shared__ uint32_t q2[3][kQ2Cap];
@@ -1162,8 +1177,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 	// r read the block's tiles a moment ago -- its L2 still has them.  Per batch: the blocks, the
 	// workgroup of the serial walks, the helpers.
 	const uint32_t nblocks = g.common.nrows - 1;
-	const bool serial = helpers == 0;   // no helpers launched (the last batches were not sample-heavy): every block does all of its sub-rows itself
-	const uint32_t nhelp = helpers;
+	const uint32_t nhelp = HELPED ? helpers : 0u;
 	const uint32_t per = (nblocks + 1 + nhelp + 7u) & ~7u, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
 	if (blk > nblocks + nhelp)
 		return;
@@ -1173,84 +1187,72 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 			side_walks(a);
 		return;
 	}
-	unsigned long long *stamp = a.stamps && blk < nblocks ? a.stamps + (size_t)(blk + 8192) * 8 : nullptr;
+	unsigned long long *stamp = kCheckStamps && a.stamps && blk < nblocks ? a.stamps + (size_t)(blk + 8192) * 8 : nullptr;
 	if (stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
-	BlockCounts bc;
-	bool own = blk < nblocks;   // a block's wave starts with the block's own row = sub-row 0
-	uint32_t own_extra = 0;
-	if (own) {
-		load_counts(a, blk, lane, bc);
-		const uint32_t ns = bc.cum[kTilesPerChecker];
-		own_extra = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
-	}
-	// The sub-rows behind the first of every block, numbered through the batch in block order (helpers;
-	// in the serial mode the blocks' waves).  A lane takes eight neighbouring blocks (sixty-four tiles:
-	// the text has at most 4096), the wave's prefix sum gives each block the number of its first sub-row.
-	uint32_t extra[8], first[8], mine = 0, base = 0, all = 0;
-#pragma unroll
-	for (uint32_t i = 0; i < 8; i++)
-		extra[i] = first[i] = 0;
-	if (!own || (serial && own_extra)) {
-		const uint4 *sc = (const uint4 *)a.scount;
-#pragma unroll
-		for (uint32_t i = 0; i < 8; i++) {
-			const uint32_t t0 = (lane * 8 + i) * kTilesPerChecker;
-			uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-			if (t0 < a.ntiles) {   // (the counts behind the last tile are whatever they are: masked below)
-				lo = sc[t0 / 4];
-				hi = sc[t0 / 4 + 1];
-			}
-			const uint32_t c[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
-			uint32_t ns = 0;
-#pragma unroll
-			for (uint32_t k = 0; k < 8; k++)
-				ns += t0 + k < a.ntiles ? c[k] : 0u;
-			extra[i] = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
-			first[i] = mine;
-			mine += extra[i];
-		}
-		base = wave_excl_sum(mine, lane, all);
-	}
-	// one loop for everything a wave does, so that the two stages are in the kernel once
-	const uint32_t step = serial ? 1u : nhelp;
-	uint32_t s0 = serial ? 0u : blk - nblocks - 1;
-	for (bool numbered = false;;) {
-		uint32_t tb = blk, tj = 0, tslot = blk + 1, tword7 = own_extra;
+	if constexpr (!HELPED) {
+		(void)check_subrow<W, true>(a, q2, lane, blk, 0, blk + 1, stamp);
+	} else {
+		// The sub-rows behind the first of every block are numbered through the batch in block order and dealt to
+		// the helper waves.  A lane takes eight neighbouring blocks (sixty-four tiles: the text has at most 4096),
+		// the wave's prefix sum gives each block the number of its first sub-row.  (The per-lane numbers live in
+		// LDS, not in sixteen registers carried through both stages.)
+		__shared__ uint32_t s_extra[8][kCheckBlock], s_first[8][kCheckBlock];
+		bool own = blk < nblocks;   // a block's wave does the block's own row = sub-row 0, nothing else
+		uint32_t base = 0, all = 0;
 		if (!own) {
-			if (numbered)
-				s0 += step;
-			numbered = true;
-			if (s0 >= all)
-				return;
-			// sub-row number s0 -> its block and index: the lane whose blocks hold it says so
-			uint32_t fb = 0, fk = 0;
-			bool found = false;
+			const uint4 *sc = (const uint4 *)a.scount;
+			uint32_t mine = 0;
 #pragma unroll
 			for (uint32_t i = 0; i < 8; i++) {
-				const uint32_t lo = base + first[i];
-				if (s0 >= lo && s0 < lo + extra[i]) {
-					found = true;
-					fb = lane * 8 + i;
-					fk = s0 - lo + 1;
+				const uint32_t t0 = (lane * 8 + i) * kTilesPerChecker;
+				uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+				if (t0 < a.ntiles) {   // (the counts behind the last tile are whatever they are: masked below)
+					lo = sc[t0 / 4];
+					hi = sc[t0 / 4 + 1];
 				}
+				const uint32_t c[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+				uint32_t ns = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < 8; k++)
+					ns += t0 + k < a.ntiles ? c[k] : 0u;
+				const uint32_t ex = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
+				s_extra[i][lane] = ex;
+				s_first[i][lane] = mine;
+				mine += ex;
 			}
-			const unsigned long long who = __ballot(found);
-			if (!who)
-				return;   // (cannot happen: every number below `all` belongs to a block)
-			const int src = (int)__builtin_ctzll(who);
-			tb = (uint32_t)__builtin_amdgcn_readlane((int)fb, src);
-			tj = (uint32_t)__builtin_amdgcn_readlane((int)fk, src);
-			if (serial && tb != blk)
-				continue;   // (serial mode: a block's wave does its own sub-rows only)
-			tslot = a.nrows + s0;
-			tword7 = 0;
-			load_counts(a, tb, lane, bc);
+			base = wave_excl_sum(mine, lane, all);
 		}
-		check_subrow<W>(a, q2, lane, tb, tj, tslot, tword7, bc, own ? stamp : nullptr);
-		if (own && !serial)
-			return;
-		own = false;
+		// one loop for everything a wave does, so that the two stages are in the kernel once
+		for (uint32_t s0 = blk - nblocks - 1;; s0 += nhelp) {
+			uint32_t tb = blk, tj = 0, tslot = blk + 1;
+			if (!own) {
+				if (s0 >= all)
+					return;
+				// sub-row number s0 -> its block and index: the lane whose blocks hold it says so
+				uint32_t fb = 0, fk = 0;
+				bool found = false;
+#pragma unroll
+				for (uint32_t i = 0; i < 8; i++) {
+					const uint32_t lo = base + s_first[i][lane];
+					if (s0 >= lo && s0 < lo + s_extra[i][lane]) {
+						found = true;
+						fb = lane * 8 + i;
+						fk = s0 - lo + 1;
+					}
+				}
+				const unsigned long long who = __ballot(found);
+				if (!who)
+					return;   // (cannot happen: every number below `all` belongs to a block)
+				const int src = (int)__builtin_ctzll(who);
+				tb = (uint32_t)__builtin_amdgcn_readlane((int)fb, src);
+				tj = (uint32_t)__builtin_amdgcn_readlane((int)fk, src);
+				tslot = a.nrows + s0;
+			}
+			(void)check_subrow<W, false>(a, q2, lane, tb, tj, tslot, own ? stamp : nullptr);
+			if (own)
+				return;
+		}
 	}
 }
 
@@ -1649,7 +1651,8 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	// slots and registers still stay free for the check and emit kernels of the batches in flight
 	// on other streams -- with bulk workgroups resident everywhere those would wait for a whole
 	// bulk workgroup to drain, every time.
-	const size_t lds = std::max((size_t)a.bloom_words * 4, (size_t)56 * 1024);
+	static const size_t lds_kb = getenv("ACM_SIEVE_LDS_KB") ? (size_t)atoi(getenv("ACM_SIEVE_LDS_KB")) : 56;   // debugging aid
+	const size_t lds = std::max((size_t)a.bloom_words * 4, lds_kb * 1024);
 	uint32_t blocks = (g.ntiles + kWaves - 1) / kWaves;
 	if (blocks > (uint32_t)d->num_cus)
 		blocks = (uint32_t)d->num_cus;
@@ -1699,12 +1702,16 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	}
 	if (after_sieve)
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
+#define ACM_CHECK(W)                                                                                                       \
+	if (helpers) hipLaunchKernelGGL((k_sieve_check<W, true>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); \
+	else hipLaunchKernelGGL((k_sieve_check<W, false>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers)
 	switch (d->sv_stride) {
-	case 8: hipLaunchKernelGGL(k_sieve_check<8>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
-	case 4: hipLaunchKernelGGL(k_sieve_check<4>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
-	case 2: hipLaunchKernelGGL(k_sieve_check<2>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
-	default: hipLaunchKernelGGL(k_sieve_check<1>, dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); break;
+	case 8: ACM_CHECK(8); break;
+	case 4: ACM_CHECK(4); break;
+	case 2: ACM_CHECK(2); break;
+	default: ACM_CHECK(1); break;
 	}
+#undef ACM_CHECK
 	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
 	if (after_emit)
 		ACM_HIP_TRY(hipEventRecord(after_emit, s));

@@ -85,17 +85,21 @@ def test_gather_planes_over_rccl(gpu, lib):
     rccl.ncclCommDestroy(comm)
 
 
-def test_bench_collective_path_at_world_size_one(gpu):
+@pytest.mark.parametrize("gather", ["torch", "abi"])
+def test_bench_collective_path_at_world_size_one(gpu, gather):
     """bench.py with the nccl process group initialised at world size 1: init, the gather of the
     planes tensor on its own stream behind the workers' scans, the barriers of the timed blocks --
-    the code the driver's multi-GPU run executes -- with parity checked by bench.py itself."""
+    the code the driver's multi-GPU run executes -- with parity checked by bench.py itself.  gather = abi: the planes
+    go through acm_gather_planes on a communicator bench.py makes for itself, and the parity check reads the
+    gathered copy."""
     env = dict(os.environ, ACM_BENCH_NCCL1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "4", "--repeats", "2",
-                        "--texts", "3", "--sub", "", "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True,
+                        "--texts", "3", "--sub", "", "--no-cpu-baseline", "--no-e2e", "--gather", gather], capture_output=True, text=True,
                        timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["parity"].startswith("bit-exact") and rec["config"]["pipeline"] == "sparse"
+    assert rec["config"]["gather"].startswith("acm_gather_planes" if gather == "abi" else "torch")
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
