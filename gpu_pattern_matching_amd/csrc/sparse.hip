@@ -1702,9 +1702,12 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	}
 	if (after_sieve)
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
+	static const char *skip = getenv("ACM_SIEVE_SKIP");   // experiment (results are void): "c" no check kernel, "e" no emit kernel
+	const bool skip_check = skip && strchr(skip, 'c'), skip_emit = skip && strchr(skip, 'e');
 #define ACM_CHECK(W)                                                                                                       \
 	if (helpers) hipLaunchKernelGGL((k_sieve_check<W, true>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); \
 	else hipLaunchKernelGGL((k_sieve_check<W, false>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers)
+	if (!skip_check)
 	switch (d->sv_stride) {
 	case 8: ACM_CHECK(8); break;
 	case 4: ACM_CHECK(4); break;
@@ -1712,7 +1715,8 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	default: ACM_CHECK(1); break;
 	}
 #undef ACM_CHECK
-	hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
+	if (!skip_emit)
+		hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
 	if (after_emit)
 		ACM_HIP_TRY(hipEventRecord(after_emit, s));
 	if (want_stamps) {   // debugging aid: where the waves spend their time (100 MHz clock)
