@@ -109,33 +109,79 @@ bool emit(const Work &w, CompactTables &t, uint32_t lds_bytes)
 	t.n = n;
 	t.ref2cid.assign(n, UINT32_MAX);
 	t.cid2ref.assign(n, 0);
-	// Compact ids: every state in trie preorder, so that a state's first child is cid + 1 -- one small
-	// delta away -- whether or not either of them keeps a full row.  A row is found through its
-	// state's record (lo16 = first cell), never through the id, so rows are numbered on their own,
-	// shallow first.
+	// Compact ids: breadth-first order -- the non-final states first, then the final ones ("final" is a compare of
+	// the code with one constant).  Breadth-first, because a record's LDS banks are its id modulo 32 and the walk
+	// is bound by the LDS as much as by its instructions: the lanes of a wave are mostly in shallow states, and
+	// numbered this way the root, its children and their children -- the states most lanes are in -- lie side by
+	// side, i.e. in different banks (in trie preorder, where a state's id depends on the sizes of the subtrees in
+	// front of it, the kernel took a third longer).  A row is found through its state's record, never
+	// through the id, so rows are numbered on their own, shallow first.
 	std::vector<uint32_t> row_of(n, UINT32_MAX);
-	uint32_t next = 0, nrows = 0;
+	uint32_t nrows = 0;
 	for (uint32_t s : a.bfs_order)
 		if (w.is_row[s])
 			row_of[s] = nrows++;
 	t.rows = nrows;
 	{
-		std::vector<uint32_t> stack(1, 0);
-		while (!stack.empty()) {
-			const uint32_t s = stack.back();
-			stack.pop_back();
-			t.ref2cid[s] = next;
-			t.cid2ref[next++] = s;
-			for (uint32_t e = a.child_begin[s + 1]; e-- > a.child_begin[s];)
-				stack.push_back(a.child_list[e].to);
+		// (One more constraint: a record that defers names its fail state by id in the field the walk adds the
+		// byte's class to for the row read -- every lane issues that read, needed or not, and a misaligned
+		// ds_read_u16 costs the whole wave instruction extra LDS cycles (+77 % LDS time measured when a quarter of
+		// the wave instructions had such a lane).  So states that are deferred TO get even ids: within each of the
+		// two classes they take the even places, the others the odd ones, as long as both kinds last.)
+		std::vector<uint8_t> target(n, 0);
+		for (uint32_t s = 0; s < n; s++)
+			if (!w.is_row[s]) {
+				uint32_t tmp[3];
+				if (w.diff(s, w.h[s], tmp, 3) > 2)
+					target[a.fail[s]] = 1;
+			}
+		const std::vector<uint32_t> &order = a.bfs_order;
+		if (order.size() != n || target[0])
+			return false;
+		uint32_t next = 0;
+		for (int pass = 0; pass < 2; pass++) {
+			if (pass == 1)
+				t.first_final = next;
+			std::vector<uint32_t> even, odd;   // deferred-to states, the others (breadth-first each)
+			for (uint32_t s : order)
+				if ((a.is_final_ref(s) ? 1 : 0) == pass)
+					(target[s] ? even : odd).push_back(s);
+			size_t ie = 0, io = 0;
+			if (pass == 0 && !odd.empty() && odd[0] == 0) {   // the root is id 0
+				t.ref2cid[0] = next;
+				t.cid2ref[next++] = 0;
+				io = 1;
+			}
+			while (ie < even.size() || io < odd.size()) {
+				uint32_t s;
+				if ((next & 1u) == 0 && ie < even.size())
+					s = even[ie++];
+				else if (io < odd.size())
+					s = odd[io++];
+				else
+					s = even[ie++];   // only deferred-to states left: some get odd ids (slower reads, nothing else)
+				t.ref2cid[s] = next;
+				t.cid2ref[next++] = s;
+			}
 		}
+		if (next != n)
+			return false;
 	}
-	if (next != n)
-		return false;
-	const uint32_t cell0 = 256 / 2;   // first cell of row 0 (the class map lies in front)
 	t.is_final.assign(n, 0);
 	for (uint32_t s = 0; s < n; s++)
 		t.is_final[t.ref2cid[s]] = a.is_final_ref(s) ? 1 : 0;
+	// the layout first: a code is the address of a record.  The class map (a compile-time LDS address for the
+	// walk), the rows behind it (a row is named by the byte address of its first cell), then the records
+	auto up = [](uint32_t v, uint32_t al) { return (v + al - 1) / al * al; };
+	t.off_cls = 0;
+	t.off_rows = 256;
+	t.off_rec = up(t.off_rows + t.rows * nc * 2, 16);
+	t.off_side = t.off_rec + n * 8;
+	t.image_bytes = up(t.off_side, 16);
+	if (t.off_rows + (size_t)t.rows * nc * 2 > kCompactSideBase || nc > 127)
+		return false;
+	if (t.image_bytes > lds_bytes)
+		return false;
 	auto code = [&](uint32_t ref) { return t.code_of_ref(ref); };
 
 	std::vector<uint64_t> rec(n, 0);
@@ -145,11 +191,11 @@ bool emit(const Work &w, CompactTables &t, uint32_t lds_bytes)
 		uint32_t cls[3] = { 0, 0, 0 };
 		uint32_t k = 0, next16;
 		if (w.is_row[s]) {
-			next16 = cell0 + row_of[s] * nc;
+			next16 = t.off_rows + row_of[s] * nc * 2;
 		} else {
 			const uint32_t f = a.fail[s], hA = w.h[s];
 			k = w.diff(s, hA, cls, 3);
-			next16 = cell0 + row_of[hA] * nc;
+			next16 = t.off_rows + row_of[hA] * nc * 2;
 			if (k > 2) {   // two overrides of its own on top of what the fail state's record says
 				k = w.diff(s, f, cls, 3);
 				next16 = kCompactSideBase + t.ref2cid[f];
@@ -162,24 +208,11 @@ bool emit(const Work &w, CompactTables &t, uint32_t lds_bytes)
 				t.side_row++;
 			}
 		}
-		const uint32_t c1 = k > 0 ? cls[0] : kCompactNoClass, t1 = k > 0 ? code(w.row(s)[cls[0]]) : 0u;
-		const uint32_t c2 = k > 1 ? cls[1] : kCompactNoClass, t2 = k > 1 ? code(w.row(s)[cls[1]]) : 0u;
+		const uint32_t c1 = k > 0 ? 2 * cls[0] : kCompactNoClass, t1 = k > 0 ? code(w.row(s)[cls[0]]) : 0u;
+		const uint32_t c2 = k > 1 ? 2 * cls[1] : kCompactNoClass, t2 = k > 1 ? code(w.row(s)[cls[1]]) : 0u;
 		rec[cid] = (uint64_t)(t1 | (c1 << 16) | (c2 << 24)) | ((uint64_t)(t2 | (next16 << 16)) << 32);
 	}
 	t.nside = 0;
-
-	auto up = [](uint32_t v, uint32_t al) { return (v + al - 1) / al * al; };
-	// the class map first (a compile-time LDS address for the walk), the rows behind it (a row is
-	// named by its first cell, counted in cells from LDS address 0), then the records
-	t.off_cls = 0;
-	t.off_rows = 256;
-	t.off_rec = up(t.off_rows + t.rows * nc * 2, 16);
-	t.off_side = t.off_rec + n * 8;
-	t.image_bytes = up(t.off_side, 16);
-	if ((t.off_rows + (size_t)t.rows * nc * 2) / 2 > kCompactSideBase)
-		return false;
-	if (t.image_bytes > lds_bytes)
-		return false;
 	t.image.assign(t.image_bytes, 0);
 	for (uint32_t s = 0; s < n; s++) {
 		if (row_of[s] == UINT32_MAX)
@@ -193,7 +226,7 @@ bool emit(const Work &w, CompactTables &t, uint32_t lds_bytes)
 		put32(t.image, t.off_rec + (size_t)c * 8 + 4, (uint32_t)(rec[c] >> 32));
 	}
 	for (uint32_t b = 0; b < 256; b++)
-		t.image[t.off_cls + b] = a.byte_class[b];
+		t.image[t.off_cls + b] = (uint8_t)(2 * a.byte_class[b]);
 	return true;
 }
 
@@ -239,20 +272,20 @@ void build_compact(const acm_automaton &a, CompactTables &t, uint32_t lds_bytes)
 uint32_t compact_step(const CompactTables &t, uint32_t e, uint8_t byte, uint32_t *hops)
 {
 	const std::vector<uint8_t> &m = t.image;
-	const uint32_t c = m[t.off_cls + byte];
-	uint32_t cid = (e & 0x7FFEu) >> 1;
+	const uint32_t c2 = m[t.off_cls + byte];   // 2 * class
+	size_t at = (size_t)(e & 0xFFFFu) << 3;    // the code is the record's address / 8
 	for (uint32_t links = 0;; links++) {
-		const uint32_t rx = get32(m, t.off_rec + (size_t)cid * 8), ry = get32(m, t.off_rec + (size_t)cid * 8 + 4);
+		const uint32_t rx = get32(m, at), ry = get32(m, at + 4);
 		if (hops)
 			*hops = links;
-		if (((rx >> 16) & 0xFFu) == c)
+		if (((rx >> 16) & 0xFFu) == c2)
 			return rx & 0xFFFFu;
-		if ((rx >> 24) == c)
+		if ((rx >> 24) == c2)
 			return ry & 0xFFFFu;
 		const uint32_t nx = ry >> 16;
 		if (nx < kCompactSideBase)
-			return get16(m, 2 * (nx + c));
-		cid = nx - kCompactSideBase;
+			return get16(m, nx + c2);
+		at = (size_t)t.off_rec + (size_t)(nx - kCompactSideBase) * 8;
 	}
 }
 
@@ -303,7 +336,7 @@ extern "C" int acm_compact_profile(const acm_automaton *a, const unsigned char *
 	memset(counts, 0, 5 * sizeof(uint64_t));
 	if (!t.ok)
 		return 0;
-	uint32_t e = 0;
+	uint32_t e = t.root_code();
 	for (size_t i = 0; i < n; i++) {
 		uint32_t hops = 0;
 		const uint32_t from = e;
@@ -311,7 +344,7 @@ extern "C" int acm_compact_profile(const acm_automaton *a, const unsigned char *
 		if (hops && getenv("ACM_COMPACT_DEBUG")) {
 			static uint64_t hist[24][4];
 			static uint64_t seen = 0;
-			const uint32_t ref = t.cid2ref[acm::CompactTables::cid_of_code(from)];
+			const uint32_t ref = t.cid2ref[t.cid_of_code(from)];
 			const uint32_t nch = a->child_begin[ref + 1] - a->child_begin[ref];
 			hist[std::min<uint32_t>(a->depth[ref], 23)][std::min<uint32_t>(nch, 3)]++;
 			if (++seen == 20000) {
@@ -323,7 +356,7 @@ extern "C" int acm_compact_profile(const acm_automaton *a, const unsigned char *
 		}
 		counts[0]++;
 		counts[hops == 0 ? 1 : hops == 1 ? 2 : 3]++;
-		counts[4] += e >> 15;
+		counts[4] += e >= t.final_code() ? 1 : 0;
 	}
 	return 1;
 }

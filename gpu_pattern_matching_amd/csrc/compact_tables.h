@@ -8,20 +8,22 @@
 // in, final ones included -- fits the 160 KiB of a CU.  The walk kernel (lds_walk.hip) then never
 // leaves the LDS: no cold plane, no wave-uniform gather branch.
 //
-//   state code   e = final << 15 | cid << 1     (16 bits; cid = compact state id < 16384; "final" is
-//                                                 the sign of the code read as an int16)
-//   cls    u8 [256]      byte -> class, at LDS address 0
-//   rows   u16 [R][NC]   full rows of R chosen states, cells are state codes; a row is named by its
-//                        first cell, counted in cells from LDS address 0
+//   state code   e = (byte address of the state's record) / 8 = off_rec / 8 + cid     (15 bits; the walk shifts it
+//                    left by three and has the address.  cid = compact state id < 16384, non-final states
+//                    first: "final" is e >= final_code)
+//   cls    u8 [256]      byte -> 2 * class, at LDS address 0
+//   rows   u16 [R][NC]   full rows of R chosen states, cells are state codes; a row is named by the BYTE address
+//                        of its first cell (even, below 0xC000: the rows end 48 KiB into the image at the latest)
 //   rec    u64 [n]       per state: up to two explicit transitions and where to look otherwise:
-//                          tgt1 | cls1 << 16 | cls2 << 24,  tgt2 | next16 << 16     (class 0xFF: none)
-//                          next16 <  0xC000: next = cell [next16 + class]   (a row)
-//                          next16 >= 0xC000: ask the record of state next16 - 0xC000 (the fail state's)
+//                          tgt1 | 2*cls1 << 16 | 2*cls2 << 24,  tgt2 | next16 << 16     (class byte 0xFF: none)
+//                          next16 <  0xC000: next = the cell at byte address next16 + 2*class   (a row)
+//                          next16 >= 0xC000: ask the record of state cid = next16 - 0xC000 (the fail state's)
 // Which states keep a row: the root, every state with more than two transitions that neither its
 // nearest row nor its fail state's record explains, and -- shallow first, while the LDS has room --
 // states that would otherwise defer to their fail state's record (a second hop for the walk).
-// Compact ids: every state in trie preorder (root = 0), so that a state's first child is cid + 1 and
-// its code one small delta away.  A row is found through its state's record, not through the id.
+// Compact ids: the non-final states in trie preorder (root = 0), then the final ones.  A row is found through
+// its state's record, not through the id.  (Every field is sized so that a step of the walk is nine vector
+// instructions: address = code << 3; cell address = next16 + 2*class in one add; targets are whole codes.)
 #pragma once
 
 #include <cstdint>
@@ -49,8 +51,13 @@ struct CompactTables {
 	// statistics of the construction
 	uint32_t promoted = 0, simple = 0, side_row = 0, side_link = 0;
 
-	uint32_t code_of_ref(uint32_t ref) const { return (ref2cid[ref] << 1) | ((uint32_t)is_final[ref2cid[ref]] << 15); }
-	static uint32_t cid_of_code(uint32_t e) { return (e & 0x7FFEu) >> 1; }
+	uint32_t first_final = 0;                 // cid of the first final state (n: none)
+
+	uint32_t code_of_cid(uint32_t cid) const { return off_rec / 8 + cid; }
+	uint32_t code_of_ref(uint32_t ref) const { return code_of_cid(ref2cid[ref]); }
+	uint32_t cid_of_code(uint32_t e) const { return (e & 0xFFFFu) - off_rec / 8; }
+	uint32_t root_code() const { return code_of_cid(0); }
+	uint32_t final_code() const { return code_of_cid(first_final); }   // codes from here on are final states
 };
 
 // Builds the tables; t.ok stays false when the set does not qualify (too many states or classes,

@@ -60,7 +60,7 @@ struct acm_dfa {
 	int32_t *d_lds_out = nullptr;        // [compact id] reported pattern index
 	uint32_t *d_lds_cid2ref = nullptr;   // [compact id] reference id
 	uint32_t *d_lds_ref2code = nullptr;  // [reference id] state code (a state handed over on the device)
-	uint32_t lds_image_bytes = 0, lds_off_rec = 0, lds_halo = 0, lds_rows = 0;
+	uint32_t lds_image_bytes = 0, lds_off_rec = 0, lds_halo = 0, lds_rows = 0, lds_root_code = 0, lds_final_code = 0;
 	std::vector<uint16_t> lds_ref2code;  // host: state code of a reference id (init_state)
 
 	bool sparse_ok = false;              // every pattern has >= 3 bytes: the sparse pipeline applies

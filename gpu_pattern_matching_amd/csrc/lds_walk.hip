@@ -62,6 +62,7 @@ struct LdsGroup {
 	const uint4 *image;       // the LDS image, image16 uint4s
 	uint32_t image16;
 	uint32_t off_rec;         // byte offset of the records in the image
+	uint32_t root_code, final_code;   // the root's code (= off_rec / 8); codes from final_code on are final states
 	const int32_t *out;       // [cid] head pattern of a final state
 	const uint32_t *cid2ref;  // [cid] reference id
 	uint32_t n, n_chains, n_tiles, hb;
@@ -69,55 +70,49 @@ struct LdsGroup {
 	LdsBatch b[kMaxGroup];
 };
 
-// One byte for C chains.  e[] are state codes (final << 15 | cid << 1) with whatever the record
-// left in the upper half: every use masks or ignores it.
+// what the walk needs to know of the code space (compact_tables.h)
+struct Codes {
+	uint32_t off_rec;   // byte address of the records
+	uint32_t root;      // code of the root = off_rec / 8
+	uint32_t fin;       // codes from here on are final states
+};
+
+// One transition by the book (the whole deferral chain followed on the spot): the edge tiles, the drains below,
+// the lanes that cannot fall further behind.
+__device__ __forceinline__ uint32_t next_code(const uint8_t *lds, uint32_t off_rec, uint32_t e, uint32_t byte)
+{
+	const uint32_t cls2 = lds[byte];   // 2 * class
+	uint32_t at = (e & 0xFFFFu) << 3, out = 0;   // the code is the record's address / 8 (codes in flight carry other fields above it)
+	for (bool more = true; more;) {
+		const uint2 q = *(const uint2 *)(lds + at);
+		more = false;
+		if (((q.x >> 16) & 0xFFu) == cls2) {
+			out = q.x & 0xFFFFu;
+		} else if ((q.x >> 24) == cls2) {
+			out = q.y & 0xFFFFu;
+		} else if (q.y < (acm::kCompactSideBase << 16)) {
+			out = *(const uint16_t *)(lds + (q.y >> 16) + cls2);
+		} else {
+			more = true;
+			at = off_rec + (((q.y >> 16) - acm::kCompactSideBase) << 3);   // the fail state's record
+		}
+	}
+	return out;
+}
+
+// One byte for C chains.  e[] are state codes (the record's byte address / 8; compact_tables.h).
 //   LIVE   the step may lie outside the chain's text (tile at either end of the text): such steps
 //          leave the state alone;  EMIT  the step belongs to the chain itself, not to its halo.
 template <int C, int K, bool LIVE, bool EMIT>
-__device__ __forceinline__ void step_all(const uint8_t *lds, uint32_t off_rec, const uint4 (&w)[C], uint32_t (&e)[C],
+__device__ __forceinline__ void step_all(const uint8_t *lds, uint32_t off_rec, uint32_t final_code, const uint4 (&w)[C], uint32_t (&e)[C],
     uint32_t (&so)[C], uint32_t *stage, uint32_t stepbits, const int32_t (&lo)[C], const int32_t (&hi)[C],
     const int32_t (&keep)[C], int32_t j)
 {
-	uint32_t cls[C];
-	uint2 r[C];
-	uint32_t cell[C];
-#pragma unroll
-	for (int c = 0; c < C; c++) {
-		const uint32_t d = (K < 4) ? w[c].x : (K < 8) ? w[c].y : (K < 12) ? w[c].z : w[c].w;
-		cls[c] = lds[(d >> (8 * (K & 3))) & 0xFFu];
-		r[c] = *(const uint2 *)(lds + off_rec + ((e[c] & 0x7FFEu) << 2));
-	}
-#pragma unroll
-	for (int c = 0; c < C; c++)
-		cell[c] = *(const uint16_t *)(lds + (((r[c].y >> 16) + cls[c]) << 1));
-	bool more[C];
-	bool any = false;
 	uint32_t nxt[C];
 #pragma unroll
 	for (int c = 0; c < C; c++) {
-		const bool m1 = ((r[c].x >> 16) & 0xFFu) == cls[c], m2 = (r[c].x >> 24) == cls[c];
-		more[c] = !m1 && !m2 && r[c].y >= (acm::kCompactSideBase << 16);
-		any |= more[c];
-		nxt[c] = m1 ? r[c].x : m2 ? r[c].y : cell[c];
-	}
-	if (__builtin_amdgcn_ballot_w64(any)) {   // a record that defers to its fail state's: the same again from there
-#pragma unroll
-		for (int c = 0; c < C; c++) {
-			uint2 q = r[c];
-			while (__builtin_amdgcn_ballot_w64(more[c])) {
-				if (more[c]) {
-					q = *(const uint2 *)(lds + off_rec + (((q.y >> 16) - acm::kCompactSideBase) << 3));
-					const bool m1 = ((q.x >> 16) & 0xFFu) == cls[c], m2 = (q.x >> 24) == cls[c];
-					more[c] = !m1 && !m2 && q.y >= (acm::kCompactSideBase << 16);
-					if (m1)
-						nxt[c] = q.x;
-					else if (m2)
-						nxt[c] = q.y;
-					else if (!more[c])
-						nxt[c] = *(const uint16_t *)(lds + (((q.y >> 16) + cls[c]) << 1));
-				}
-			}
-		}
+		const uint32_t d = (K < 4) ? w[c].x : (K < 8) ? w[c].y : (K < 12) ? w[c].z : w[c].w;
+		nxt[c] = next_code(lds, off_rec, e[c], (d >> (8 * (K & 3))) & 0xFFu);
 	}
 #pragma unroll
 	for (int c = 0; c < C; c++) {
@@ -125,36 +120,13 @@ __device__ __forceinline__ void step_all(const uint8_t *lds, uint32_t off_rec, c
 			nxt[c] = e[c];   // in front of where this chain's walk starts, or past the end of the text: freeze
 		e[c] = nxt[c];
 		if (EMIT) {
-			const bool hit = (int16_t)(uint16_t)e[c] < 0 && (!LIVE || (j >= keep[c] && j < hi[c]));
+			const bool hit = e[c] >= final_code && (!LIVE || (j >= keep[c] && j < hi[c]));
 			if (hit) {
-				stage[so[c]] = (e[c] & 0xFFFFu) | stepbits;
+				stage[so[c]] = e[c] | stepbits;
 				so[c] += 64;
 			}
 		}
 	}
-}
-
-// One transition by the book (the whole deferral chain followed on the spot): the drains below, the
-// lanes that cannot fall further behind, and nothing else.
-__device__ __forceinline__ uint32_t next_code(const uint8_t *lds, uint32_t off_rec, uint32_t e, uint32_t byte)
-{
-	const uint32_t cls = lds[byte];
-	uint32_t cid2 = e & 0x7FFEu, out = 0;
-	bool open = true;
-	while (open) {
-		const uint2 q = *(const uint2 *)(lds + off_rec + (cid2 << 2));
-		const bool m1 = ((q.x >> 16) & 0xFFu) == cls, m2 = (q.x >> 24) == cls;
-		if (m1 || m2) {
-			out = (m1 ? q.x : q.y) & 0xFFFFu;
-			open = false;
-		} else if (q.y < (acm::kCompactSideBase << 16)) {
-			out = *(const uint16_t *)(lds + (((q.y >> 16) + cls) << 1));
-			open = false;
-		} else {
-			cid2 = (q.y >> 15) & 0x7FFEu;   // 2 * (next16 - 0xC000): the fail state's record
-		}
-	}
-	return out;
 }
 
 // The step for two chains, written out.  (The compiler's version of step_all spends more on moving
@@ -171,49 +143,51 @@ __device__ __forceinline__ uint32_t next_code(const uint8_t *lds, uint32_t off_r
 // {code, step - bytes behind} in the lane's list, 256 bytes further for every record.
 template <int R, bool EMIT>
 __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t hiB, uint32_t loB, uint32_t inA, uint32_t inB,
-    uint32_t &eA, uint32_t &eB, uint32_t &ndA, uint32_t &ndB, uint32_t &soA, uint32_t &soB, uint32_t off_rec,
-    uint32_t stepconst, uint32_t *stage, uint64_t &slowA, uint64_t &slowB)
+    uint32_t &eA, uint32_t &eB, uint32_t &ndA, uint32_t &ndB, uint32_t &soA, uint32_t &soB,
+    uint32_t root_code, uint32_t final_code, uint32_t stepconst, uint32_t *stage, uint64_t &slowA, uint64_t &slowB)
 {
 	uint64_t m1A, m2A, m1B, m2B, moreA, moreB, sv;
 	uint32_t t0, t1, t2, t3, clsA, clsB;
-	const uint32_t c0 = acm::kCompactSideBase << 16, ffff = 0xFFFFu;
+	const uint32_t c0 = acm::kCompactSideBase << 16, kfix = root_code - acm::kCompactSideBase, ffff = 0xFFFFu;
+	// Nine vector instructions per chain and byte (+ four where records are emitted): byte select (2), record
+	// address = low half of the code * 8 (v_mad_u32_u16: the codes in flight carry other fields of the
+	// records in their upper halves), cell address = next16 + 2*class in one add, three compares into scalar pairs,
+	// two selects.  (Compares into VCC + SDWA selects would give clean codes and a one-instruction record,
+	// v_add3 -- and make the walk a third slower: every VCC hand-over between vector and scalar unit stalls
+	// the wave.)
 #define ACM_WALK(sel)                                                                                              \
 	"v_add_u32 %[t0], " sel ", %[ndA]\n\t"                                                                      \
 	"v_perm_b32 %[t0], %[hiA], %[loA], %[t0]\n\t"                                                               \
-	"v_and_b32 %[t1], 0x7ffe, %[inA]\n\t"                                                                       \
-	"v_lshl_add_u32 %[t1], %[t1], 2, %[orec]\n\t"                                                               \
+	"v_mad_u32_u16 %[t1], %[inA], 8, 0\n\t"                                                                     \
 	"ds_read_u8 %[clsA], %[t0]\n\t"                                                                             \
-	"ds_read_b64 v[84:85], %[t1]\n\t"                                                                         \
+	"ds_read_b64 v[84:85], %[t1]\n\t"                                                                           \
 	"v_add_u32 %[t2], " sel ", %[ndB]\n\t"                                                                      \
 	"v_perm_b32 %[t2], %[hiB], %[loB], %[t2]\n\t"                                                               \
-	"v_and_b32 %[t3], 0x7ffe, %[inB]\n\t"                                                                       \
-	"v_lshl_add_u32 %[t3], %[t3], 2, %[orec]\n\t"                                                               \
+	"v_mad_u32_u16 %[t3], %[inB], 8, 0\n\t"                                                                     \
 	"ds_read_u8 %[clsB], %[t2]\n\t"                                                                             \
-	"ds_read_b64 v[86:87], %[t3]\n\t"                                                                         \
+	"ds_read_b64 v[86:87], %[t3]\n\t"                                                                           \
 	"s_waitcnt lgkmcnt(2)\n\t"                                                                                  \
 	"v_add_u32_sdwa %[t0], %[clsA], v85 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
-	"v_lshlrev_b32 %[t0], 1, %[t0]\n\t"                                                                         \
 	"ds_read_u16 %[t0], %[t0]\n\t"                                                                              \
-	"v_cmp_eq_u32_sdwa %[m1A], v84, %[clsA] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
-	"v_cmp_eq_u32_sdwa %[m2A], v84, %[clsA] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
-	"v_cmp_le_u32_e64 %[moreA], %[c0], v85\n\t"                                                                \
+	"v_cmp_eq_u32_sdwa %[m1A], v84, %[clsA] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                 \
+	"v_cmp_eq_u32_sdwa %[m2A], v84, %[clsA] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                 \
+	"v_cmp_le_u32_e64 %[moreA], %[c0], v85\n\t"                                                                 \
 	"s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
 	"v_add_u32_sdwa %[t2], %[clsB], v87 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
-	"v_lshlrev_b32 %[t2], 1, %[t2]\n\t"                                                                         \
 	"ds_read_u16 %[t2], %[t2]\n\t"                                                                              \
-	"v_cmp_eq_u32_sdwa %[m1B], v86, %[clsB] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                \
-	"v_cmp_eq_u32_sdwa %[m2B], v86, %[clsB] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                \
-	"v_cmp_le_u32_e64 %[moreB], %[c0], v87\n\t"                                                                \
+	"v_cmp_eq_u32_sdwa %[m1B], v86, %[clsB] src0_sel:BYTE_2 src1_sel:DWORD\n\t"                                 \
+	"v_cmp_eq_u32_sdwa %[m2B], v86, %[clsB] src0_sel:BYTE_3 src1_sel:DWORD\n\t"                                 \
+	"v_cmp_le_u32_e64 %[moreB], %[c0], v87\n\t"                                                                 \
 	"s_mov_b64 %[slowA], 0\n\t"                                                                                 \
 	"s_mov_b64 %[slowB], 0\n\t"                                                                                 \
 	"s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
-	"v_cndmask_b32_e64 %[eA], %[t0], v85, %[m2A]\n\t"                                                          \
-	"v_cndmask_b32_e64 %[eA], %[eA], v84, %[m1A]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eA], %[t0], v85, %[m2A]\n\t"                                                           \
+	"v_cndmask_b32_e64 %[eA], %[eA], v84, %[m1A]\n\t"                                                           \
 	"s_or_b64 %[m1A], %[m1A], %[m2A]\n\t"                                                                       \
 	"s_andn2_b64 %[moreA], %[moreA], %[m1A]\n\t"                                                                \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
-	"v_cndmask_b32_e64 %[eB], %[t2], v87, %[m2B]\n\t"                                                          \
-	"v_cndmask_b32_e64 %[eB], %[eB], v86, %[m1B]\n\t"                                                          \
+	"v_cndmask_b32_e64 %[eB], %[t2], v87, %[m2B]\n\t"                                                           \
+	"v_cndmask_b32_e64 %[eB], %[eB], v86, %[m1B]\n\t"                                                           \
 	"s_or_b64 %[m1B], %[m1B], %[m2B]\n\t"                                                                       \
 	"s_andn2_b64 %[moreB], %[moreB], %[m1B]\n\t"                                                                \
 	"s_or_b64 %[sv], %[moreA], %[moreB]\n\t"                                                                    \
@@ -224,16 +198,18 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 	"s_and_b64 %[slowB], %[slowB], %[moreB]\n\t"                                                                \
 	"s_andn2_b64 %[m1A], %[moreA], %[slowA]\n\t"                                                                \
 	"s_andn2_b64 %[m1B], %[moreB], %[slowB]\n\t"                                                                \
-	"v_lshrrev_b32 %[t1], 15, v85\n\t"                                                                         \
-	"v_lshrrev_b32 %[t3], 15, v87\n\t"                                                                         \
+	"v_lshrrev_b32 %[t1], 16, v85\n\t"                                                                          \
+	"v_lshrrev_b32 %[t3], 16, v87\n\t"                                                                          \
+	"v_add_u32 %[t1], %[kfix], %[t1]\n\t"                                                                       \
+	"v_add_u32 %[t3], %[kfix], %[t3]\n\t"                                                                       \
 	"v_cndmask_b32_e64 %[eA], %[eA], %[t1], %[m1A]\n\t"                                                         \
 	"v_cndmask_b32_e64 %[eB], %[eB], %[t3], %[m1B]\n\t"                                                         \
 	"v_subb_co_u32_e64 %[ndA], %[m2A], %[ndA], 0, %[m1A]\n\t"                                                   \
 	"v_subb_co_u32_e64 %[ndB], %[m2B], %[ndB], 0, %[m1B]\n\t"                                                   \
 	".Lnodefer%=:\n\t"
 #define ACM_EMIT                                                                                                   \
-	"v_cmp_gt_i16_e64 %[m2A], 0, %[eA]\n\t"                                                                     \
-	"v_cmp_gt_i16_e64 %[m2B], 0, %[eB]\n\t"                                                                     \
+	"v_cmp_le_u16_e64 %[m2A], %[fc], %[eA]\n\t"                                                                 \
+	"v_cmp_le_u16_e64 %[m2B], %[fc], %[eB]\n\t"                                                                 \
 	"s_andn2_b64 %[m2A], %[m2A], %[moreA]\n\t"                                                                  \
 	"s_andn2_b64 %[m2B], %[m2B], %[moreB]\n\t"                                                                  \
 	"s_mov_b64 %[sv], exec\n\t"                                                                                 \
@@ -254,7 +230,8 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 	  [m1A] "=&s"(m1A), [m2A] "=&s"(m2A), [m1B] "=&s"(m1B), [m2B] "=&s"(m2B), [moreA] "=&s"(moreA),             \
 	  [moreB] "=&s"(moreB), [slowA] "=&s"(slowA), [slowB] "=&s"(slowB), [sv] "=&s"(sv)                          \
 	: [hiA] "v"(hiA), [loA] "v"(loA), [hiB] "v"(hiB), [loB] "v"(loB), [inA] "v"(inA), [inB] "v"(inB),            \
-	  [orec] "s"(off_rec), [c0] "s"(c0), [ffff] "s"(ffff), [sc] "s"(stepconst), [base] "s"(stage)                \
+	  [kfix] "s"(kfix), [c0] "s"(c0), [fc] "s"(final_code), [ffff] "s"(ffff), [sc] "s"(stepconst), \
+	  [base] "s"(stage)                                                                                            \
 	: "v84", "v85", "v86", "v87", "memory", "scc"
 	// selector of v_perm: byte nd + r of {hi, lo} (lo = bytes 0..3), the other three bytes of the result zero
 	if (EMIT) {
@@ -275,7 +252,7 @@ __device__ __forceinline__ void step2_asm(uint32_t hiA, uint32_t loA, uint32_t h
 
 // byte K of the 16 a lane holds of each of its two chains (prev: the last dword of the group in front)
 template <int K, bool EMIT>
-__device__ __forceinline__ void step_pair(const uint8_t *lds, uint32_t off_rec, const uint4 (&w)[2], const uint32_t (&prev)[2],
+__device__ __forceinline__ void step_pair(const uint8_t *lds, const Codes &k, const uint4 (&w)[2], const uint32_t (&prev)[2],
     uint32_t (&e)[2], uint32_t (&nd)[2], uint32_t (&so)[2], uint32_t *stage, uint32_t step, uint32_t lane)
 {
 	constexpr int Q = K >> 2, R = K & 3;
@@ -285,7 +262,7 @@ __device__ __forceinline__ void step_pair(const uint8_t *lds, uint32_t off_rec, 
 	const uint32_t loB = Q == 0 ? prev[1] : Q == 1 ? w[1].x : Q == 2 ? w[1].y : w[1].z;
 	const uint32_t inA = e[0], inB = e[1];   // (the step writes new registers: no copies)
 	uint64_t slowA, slowB;
-	step2_asm<R, EMIT>(hiA, loA, hiB, loB, inA, inB, e[0], e[1], nd[0], nd[1], so[0], so[1], off_rec, (step - 4u) << 16, stage,
+	step2_asm<R, EMIT>(hiA, loA, hiB, loB, inA, inB, e[0], e[1], nd[0], nd[1], so[0], so[1], k.root, k.fin, (step - 4u) << 16, stage,
 	    slowA, slowB);
 	if (slowA | slowB) {   // a lane four bytes behind deferred again: its transition by the book, no falling further behind
 		const uint32_t in[2] = { inA, inB }, lw[2] = { loA, loB };
@@ -293,8 +270,8 @@ __device__ __forceinline__ void step_pair(const uint8_t *lds, uint32_t off_rec, 
 #pragma unroll
 		for (int c = 0; c < 2; c++)
 			if ((slow[c] >> lane) & 1ull) {
-				e[c] = next_code(lds, off_rec, in[c], (lw[c] >> (8 * R)) & 0xFFu);   // four behind: byte r of the dword in front
-				if (EMIT && (int16_t)(uint16_t)e[c] < 0) {
+				e[c] = next_code(lds, k.off_rec, in[c], (lw[c] >> (8 * R)) & 0xFFu);   // four behind: byte r of the dword in front
+				if (EMIT && e[c] >= k.fin) {
 					*(uint32_t *)((char *)stage + so[c]) = e[c] | ((step - 4u) << 16);
 					so[c] += 256;
 				}
@@ -305,14 +282,14 @@ __device__ __forceinline__ void step_pair(const uint8_t *lds, uint32_t off_rec, 
 // The lanes that are behind take the bytes they have not looked at yet -- the last 4 - nd of the group
 // just walked (lastw: its last dword) -- by the book; afterwards every lane is level (nd = 4).
 template <bool EMIT>
-__device__ __forceinline__ void drain(const uint8_t *lds, uint32_t off_rec, uint32_t lastw, uint32_t &e, uint32_t &nd, uint32_t &so,
+__device__ __forceinline__ void drain(const uint8_t *lds, const Codes &k, uint32_t lastw, uint32_t &e, uint32_t &nd, uint32_t &so,
     uint32_t *stage, uint32_t end_step)
 {
 	uint32_t d = 4u - nd;
 	while (__builtin_amdgcn_ballot_w64(d != 0)) {
 		if (d != 0) {
-			e = next_code(lds, off_rec, e, (lastw >> (8 * (4u - d))) & 0xFFu);
-			if (EMIT && (int16_t)(uint16_t)e < 0) {
+			e = next_code(lds, k.off_rec, e, (lastw >> (8 * (4u - d))) & 0xFFu);
+			if (EMIT && e >= k.fin) {
 				*(uint32_t *)((char *)stage + so) = e | ((end_step - d) << 16);
 				so += 256;
 			}
@@ -328,7 +305,8 @@ template <int NG>
 __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch &b, const uint8_t *lds, uint32_t wt, uint32_t lane)
 {
 	constexpr int C = 2;
-	const uint32_t hb = g.hb, off_rec = g.off_rec;
+	const uint32_t hb = g.hb;
+	const Codes k = { g.off_rec, g.root_code, g.final_code };
 	uint32_t e[C], so[C], so0[C], nd[C], chain[C], prev[C];
 	// (wave-uniform, but derived from the thread index: pinned to scalar registers for the stores' base operand)
 	const uint64_t sp = (uint64_t)(uintptr_t)(b.stage + (size_t)wt * (C * kChainBytes * 64));
@@ -343,7 +321,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 	for (int c = 0; c < C; c++) {
 		chain[c] = (wt * C + c) * 64 + lane;
 		const uint32_t base = chain[c] << kLogChain;
-		e[c] = 0;
+		e[c] = k.root;
 		nd[c] = 4;
 		prev[c] = 0;
 		so0[c] = so[c] = ((uint32_t)c * (kChainBytes * 64) + lane) * 4;   // byte offset into the tile's staging area
@@ -372,7 +350,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 			else w[c] = p5[c];                                               \
 		}                                                                        \
 	}
-#define ACM_STEP(K, EM) step_pair<K, EM>(lds, off_rec, w, prev, e, nd, so, stage, s0 + (K), lane)
+#define ACM_STEP(K, EM) step_pair<K, EM>(lds, k, w, prev, e, nd, so, stage, s0 + (K), lane)
 #define ACM_STEPS(EM) ACM_STEP(0, EM); ACM_STEP(1, EM); ACM_STEP(2, EM); ACM_STEP(3, EM); ACM_STEP(4, EM); ACM_STEP(5, EM); \
 	ACM_STEP(6, EM); ACM_STEP(7, EM); ACM_STEP(8, EM); ACM_STEP(9, EM); ACM_STEP(10, EM); ACM_STEP(11, EM); ACM_STEP(12, EM); \
 	ACM_STEP(13, EM); ACM_STEP(14, EM); ACM_STEP(15, EM)
@@ -387,8 +365,8 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		prev[1] = w[1].w;
 	}
 	if (hg) {
-		drain<false>(lds, off_rec, w[0].w, e[0], nd[0], so[0], stage, 0);
-		drain<false>(lds, off_rec, w[1].w, e[1], nd[1], so[1], stage, 0);
+		drain<false>(lds, k, w[0].w, e[0], nd[0], so[0], stage, 0);
+		drain<false>(lds, k, w[1].w, e[1], nd[1], so[1], stage, 0);
 	}
 	if (chain[0] == 0)
 		e[0] = b.init_ptr ? *b.init_ptr : b.init_code;   // the text's first chain starts at byte 0, in the carried-in state
@@ -400,8 +378,8 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		prev[0] = w[0].w;
 		prev[1] = w[1].w;
 	}
-	drain<true>(lds, off_rec, w[0].w, e[0], nd[0], so[0], stage, kChainBytes);
-	drain<true>(lds, off_rec, w[1].w, e[1], nd[1], so[1], stage, kChainBytes);
+	drain<true>(lds, k, w[0].w, e[0], nd[0], so[0], stage, kChainBytes);
+	drain<true>(lds, k, w[1].w, e[1], nd[1], so[1], stage, kChainBytes);
 #undef ACM_STEPS
 #undef ACM_STEP
 #undef ACM_PICK
@@ -425,6 +403,7 @@ template <int C, bool LIVE, int NG = 6>
 __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, const uint8_t *lds, uint32_t wt, uint32_t lane)
 {
 	const uint32_t hb = g.hb, off_rec = g.off_rec;
+	const uint32_t final_code = g.final_code;
 	uint32_t e[C], so[C], so0[C], chain[C];
 	int32_t lo[C], hi[C], keep[C];
 	uint32_t *stage = b.stage + (size_t)wt * (C * kChainBytes * 64);
@@ -445,7 +424,7 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 		hi[c] = (int32_t)(hb + len);
 		// records in front of drop_before belong to the shard's halo (acm_scan_shard_async)
 		keep[c] = (int32_t)hb + (b.drop_before > base ? (int32_t)min(b.drop_before - base, kChainBytes) : 0);
-		e[c] = base <= hb ? (b.init_ptr ? *b.init_ptr : b.init_code) : 0u;   // a chain this close to the start begins at byte 0, in the carried-in state
+		e[c] = base <= hb ? (b.init_ptr ? *b.init_ptr : b.init_code) : g.root_code;   // a chain this close to the start begins at byte 0, in the carried-in state
 		so0[c] = so[c] = (uint32_t)c * (kChainBytes * 64) + lane;
 		// all of the lane's text up front, a chain's loads back to back (scan.hip, walk_tile PRE: taken a
 		// group per trip, a 64-byte line is fetched by four loads microseconds apart -- and again)
@@ -479,7 +458,7 @@ __device__ __forceinline__ void walk_tile(const LdsGroup &g, const LdsBatch &b, 
 			else w[c] = p5[c];                                               \
 		}                                                                        \
 	}
-#define ACM_STEP(K, EM) step_all<C, K, LIVE, EM>(lds, off_rec, w, e, so, stage, sb + ((uint32_t)(K) << 16), lo, hi, keep, j0 + (K))
+#define ACM_STEP(K, EM) step_all<C, K, LIVE, EM>(lds, off_rec, final_code, w, e, so, stage, sb + ((uint32_t)(K) << 16), lo, hi, keep, j0 + (K))
 #define ACM_STEPS(EM) ACM_STEP(0, EM); ACM_STEP(1, EM); ACM_STEP(2, EM); ACM_STEP(3, EM); ACM_STEP(4, EM); ACM_STEP(5, EM); \
 	ACM_STEP(6, EM); ACM_STEP(7, EM); ACM_STEP(8, EM); ACM_STEP(9, EM); ACM_STEP(10, EM); ACM_STEP(11, EM); ACM_STEP(12, EM); \
 	ACM_STEP(13, EM); ACM_STEP(14, EM); ACM_STEP(15, EM)
@@ -624,7 +603,7 @@ __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 				rec[i] = list[min(k + i, c - 1) * 64];
 #pragma unroll
 			for (uint32_t i = 0; i < 4; i++)
-				pat[i] = outp[(rec[i] & 0x7FFEu) >> 1];
+				pat[i] = outp[(rec[i] & 0xFFFFu) - g.root_code];
 #pragma unroll
 			for (uint32_t i = 0; i < 4; i++)
 				if (k + i < c && d + i + 2 < b.plane_capacity) {
@@ -635,7 +614,7 @@ __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 		}
 	}
 	if (blk == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
-		const int32_t last_ref = (int32_t)g.cid2ref[(b.misc[0] & 0x7FFEu) >> 1];
+		const int32_t last_ref = (int32_t)g.cid2ref[(b.misc[0] & 0xFFFFu) - g.root_code];
 		b.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
 		uint32_t tail = total + 1;
 		if (tail > b.plane_capacity - 1)
@@ -749,7 +728,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void 
 		}
 #pragma unroll
 		for (uint32_t i = 0; i < kSlots; i++)
-			pat[i] = r0 + i < tot ? outp[(rec[i] & 0x7FFEu) >> 1] : 0;
+			pat[i] = r0 + i < tot ? outp[(rec[i] & 0xFFFFu) - g.root_code] : 0;
 #pragma unroll
 		for (uint32_t i = 0; i < kSlots; i++) {
 			const uint32_t idx = r0 + i;
@@ -763,7 +742,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void 
 		}
 	}
 	if (blk == 0 && tid == 0) {   // header and trailer cells (compactarray.cl:49-55)
-		const int32_t last_ref = (int32_t)g.cid2ref[(b.misc[0] & 0x7FFEu) >> 1];
+		const int32_t last_ref = (int32_t)g.cid2ref[(b.misc[0] & 0xFFFFu) - g.root_code];
 		b.misc[2] = (uint32_t)ACM_SCAN_MODE_CHAIN;   // acm_scan_path_taken
 		uint32_t tail = total + 1;
 		if (tail > b.plane_capacity - 1)
@@ -822,6 +801,8 @@ int lds_walk_prepare(const acm_automaton *a, acm_dfa *d)
 		return rc;
 	d->lds_image_bytes = t.image_bytes;
 	d->lds_off_rec = t.off_rec;
+	d->lds_root_code = t.root_code();
+	d->lds_final_code = t.final_code();
 	d->lds_halo = hb;
 	d->lds_rows = t.rows;
 	d->lds_ref2code.resize(t.n);
@@ -856,6 +837,8 @@ int lds_walk_enqueue(const acm_dfa *d, const LdsJob *jobs, uint32_t count, hipSt
 	g.image = (const uint4 *)d->d_lds_image;
 	g.image16 = d->lds_image_bytes / 16;
 	g.off_rec = d->lds_off_rec;
+	g.root_code = d->lds_root_code;
+	g.final_code = d->lds_final_code;
 	g.out = d->d_lds_out;
 	g.cid2ref = d->d_lds_cid2ref;
 	g.n = (uint32_t)n;
