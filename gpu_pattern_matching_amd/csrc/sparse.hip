@@ -972,7 +972,9 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 #pragma unroll
 								for (uint32_t k = 0; k < S; k++) {
 									const bool lok = k * W >= W - 1 || left;
-									const uint32_t reach = k * W + g.common.D;   // the candidate range ends here, counted from the lane's first byte
+									constexpr uint32_t kD = acm::kSieveMaxPrefix;   // (the largest D there is: a compile-time bound -- with the run-time D in here the kernel took 106 registers instead of 94, too many for a check wave to fit next to two bulk workgroups)
+									static_assert(kD <= 10, "the neighbours' tails looked at here reach 8 bytes beyond the lane's own 16");
+									const uint32_t reach = k * W + kD;   // the candidate range ends here at the latest, counted from the lane's first byte
 									const bool rok = reach <= 16 || (reach <= 20 ? right4 : reach <= 24 ? right8 : false);
 									if (lok && rok)
 										fj &= ~(1u << k);
