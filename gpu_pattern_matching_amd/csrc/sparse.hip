@@ -1297,6 +1297,9 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t x, uint32_t *lds, u
 // the instruction count of 1024 threads that matters here.)
 // Rows in position order: the walker's, then block by block the block's own row and its sub-rows
 // (k_sieve_check), kEmitBlock rows a round -- one round unless the text is sample-heavy.
+// PLAIN: the check kernel ran without helper waves, i.e. no block has sub-rows: rows = static rows = threads.
+// (Known at compile time, the kernel needs 40 registers instead of 75.)
+template <bool PLAIN>
 __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 {
 	const uint32_t per = gridDim.x / g.count, bi = blockIdx.x / per, blk = blockIdx.x - bi * per;
@@ -1334,7 +1337,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		}
 	}
 	uint32_t my_samples = al0.z, rows_all;
-	const uint32_t extra = tid == 0 ? 0u : al0.w & 0xFFFFu;   // (row 0 is the walker's: its word says nothing)
+	const uint32_t extra = PLAIN || tid == 0 ? 0u : al0.w & 0xFFFFu;   // (row 0 is the walker's: its word says nothing)
 	const uint32_t ord = block_exclusive<false>(tid < statics ? 1u + extra : 0u, lds, &rows_all);
 	if (tid < statics) {
 		s_ord[tid] = ord;
@@ -1352,7 +1355,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	__syncthreads();
 	if (stamp)
 		stamp[1] = __builtin_amdgcn_s_memrealtime();
-	const bool plain = rows_all == statics;   // no sub-rows: row = thread, everything is loaded already
+	const bool plain = PLAIN || rows_all == statics;   // no sub-rows: row = thread, everything is loaded already
 	uint32_t carry_in = 0, cell_in = 0;
 	unsigned long long alive = ~0ull;
 	bool gave_any = false;
@@ -1363,7 +1366,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		RowRef rr;
 		rr.slot = tid;
 		rr.lbase = tid * a.cap;
-		if (!plain) {
+		if (!PLAIN && !plain) {
 			// the static row this row belongs to: the last one whose place is not behind o
 			uint32_t lo = 0, hi = statics;
 			while (hi - lo > 1) {
@@ -1717,8 +1720,12 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	default: ACM_CHECK(1); break;
 	}
 #undef ACM_CHECK
-	if (!skip_emit)
-		hipLaunchKernelGGL(k_sieve_emit, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
+	if (!skip_emit) {
+		if (helpers)
+			hipLaunchKernelGGL(k_sieve_emit<false>, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
+		else
+			hipLaunchKernelGGL(k_sieve_emit<true>, dim3(eblocks * count), dim3(kEmitBlock), 0, s, grp);
+	}
 	if (after_emit)
 		ACM_HIP_TRY(hipEventRecord(after_emit, s));
 	if (want_stamps) {   // debugging aid: where the waves spend their time (100 MHz clock)
