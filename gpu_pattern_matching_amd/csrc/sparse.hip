@@ -134,6 +134,7 @@ struct SieveArgs {
 	const int32_t *out;
 	const uint32_t *dev2ref;
 	uint32_t F, D;
+	uint32_t nt_loads;            // bulk kernel: the text with the streaming hint
 	uint32_t tail_walk;           // bytes side_walks() walks from the root at the end of the text: D - 1, or W + 4 with 6-byte filter keys
 	uint32_t run_ok[8];           // bit b: D copies of byte b are a trie path (a run of b can start a pattern)
 	// text
@@ -758,6 +759,10 @@ __device__ __forceinline__ void load16(v4u &dst, const v4u *p)
 {
 	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
 }
+__device__ __forceinline__ void load16_nt(v4u &dst, const v4u *p)   // the same with the streaming hint
+{
+	asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
 __device__ __forceinline__ void load4(uint32_t &dst, const uint32_t *p)
 {
 	asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p));
@@ -812,9 +817,13 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 	constexpr int PER = NEXT ? 2 : 1;   // load instructions per group
 	// the groups of the sub-block at 'off' of 'tile'.  Always exactly LOADS * PER load instructions,
 	// whatever exists of the tile (what does not exist is read at the start of the text and masked
-	// out): the waits count them.  Plain loads, not non-temporal ones: the check kernel comes back
-	// for the text around every flagged sample and finds it in the cache hierarchy (with the nt hint
-	// the bench line is 7 % lower: 3.98 vs 4.29 TB/s).
+	// out): the waits count them.  With the streaming hint (nt): a read-only stream of this shape reaches
+	// 6.0 TB/s with plain loads and 6.9 with the hint on this part (tools/micro/readbw.hip), and this kernel 5.4
+	// against 5.7 (check and emit kernels off), the job 3.83 against 4.04 TB/s.  (Round 2 found plain loads
+	// 7 % better -- on 320 MiB of texts, which the Infinity Cache then kept in part for the check kernel's
+	// look at the bytes around every flagged sample; with the texts truly streamed from HBM there is
+	// nothing to keep.  ACM_SIEVE_NT=0 brings the plain loads back.)
+	const bool nt_loads = __builtin_amdgcn_readfirstlane((int)g.common.nt_loads) != 0;
 	auto issue = [&](const BulkBatch &a, uint32_t tile, uint32_t off) {
 		const uint32_t n16 = a.n_pad >> 4;
 		const uint32_t *text32 = (const uint32_t *)a.text16;
@@ -825,7 +834,10 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 			const uint32_t g16 = ((tile * a.tile_bytes + rel) >> 4) + lane;   // wraps only for tiles that do not exist
 			const bool ok = tile < a.ntiles && rel < a.tile_bytes && g16 < n16;
 			present |= (ok ? 1u : 0u) << j;
-			load16(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
+			if (nt_loads)
+				load16_nt(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
+			else
+				load16(w[j], (const v4u *)a.text16 + (ok ? g16 : 0u));
 			if (NEXT)
 				load4(nx[j], text32 + (ok && g16 + 1 < n16 ? (size_t)g16 * 4 + 4 : 0));
 			else
@@ -1571,6 +1583,8 @@ void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
 	a.dev2ref = d->d_dev2ref;
 	a.F = d->first_final;
 	a.D = d->sv_prefix_len;
+	static const uint32_t nt = getenv("ACM_SIEVE_NT") ? (uint32_t)atoi(getenv("ACM_SIEVE_NT")) : 1u;   // debugging aid: 0 = plain loads
+	a.nt_loads = nt;
 	a.tail_walk = a.D - 1;
 	if (d->sv_gram_len == 6)
 		a.tail_walk = std::max(a.tail_walk, d->sv_stride + 4);
