@@ -113,8 +113,8 @@ constexpr uint32_t kMaxRows = kMaxTiles / kTilesPerChecker + 1;   // static rows
 // the emit kernel a sub-row is a row like any other.
 constexpr uint32_t kSubRow = 256;
 constexpr uint32_t kSubRowMin = 128;       // the smallest ACM_SIEVE_SUBROW (debugging aid) may ask for: the workspace is laid out for it
-constexpr uint32_t kHelperWaves = 2048;    // waves per batch that do nothing but sub-rows, launched for sample-heavy streams only (512: 212 us for the
-                                           // worst 32 MiB of a real binary x 15000 signatures, 1024: 147, 2048: 106; sub-rows of 128 samples: no better)
+constexpr uint32_t kHelperWaves = 4096;    // waves per batch that do nothing but sub-rows, launched for sample-heavy streams only (512: 212 us for the
+                                           // worst 32 MiB of a real binary x 15000 signatures, 1024: 147, 2048: 106, 4096: 102 and the second-worst piece 91 -> 76, 8192: the same; sub-rows of 128 samples: no better)
 
 struct SieveArgs {
 	// tables
