@@ -6,7 +6,8 @@
 // shallow states (and the few that branch) keep a full row; every other state is a 4-byte record
 // "one override, else look in THAT row", and the whole automaton -- every state the walk can be
 // in, final ones included -- fits the 160 KiB of a CU.  The walk kernel (lds_walk.hip) then never
-// leaves the LDS: no cold plane, no wave-uniform gather branch.
+// leaves the LDS: no cold plane, no wave-uniform gather branch.  (160 KiB less 2 KiB: the few words of LDS a
+// scatter workgroup needs to run beside the walk.)
 //
 //   state code   e = (byte address of the state's record) / 8 = off_rec / 8 + cid     (15 bits; the walk shifts it
 //                    left by three and has the address.  cid = compact state id < 16384, non-final states

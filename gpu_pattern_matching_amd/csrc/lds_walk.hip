@@ -34,11 +34,6 @@ namespace {
 
 constexpr int kWalkBlock = 1024;               // 16 waves: the whole CU (the image takes all of its LDS)
 constexpr int kWalkWaves = kWalkBlock / 64;
-// chains per scatter workgroup.  Every workgroup adds up the tile totals in front of it, which speaks for few, large
-// ones; but 512 threads of 64 registers are what fits a CU next to a walk workgroup of 16 waves x 96 registers (and
-// the few bytes of LDS the image leaves), so that the scatter of one stream's batches runs in the shadow of the
-// next stream's walk.
-constexpr int kScatterBlockDefault = 0;   // 0: k_lds_scatter_wide
 constexpr uint32_t kChainBytes = 64, kLogChain = 6;
 constexpr uint32_t kMaxHaloGroups = 2;         // hb <= 32: patterns of up to 33 bytes
 constexpr uint32_t kGroups = kChainBytes / 16 + kMaxHaloGroups;   // 16-byte groups a lane holds per chain
@@ -631,15 +626,13 @@ __global__ __launch_bounds__(kScatterBlock) void k_lds_scatter(LdsGroup g)
 // the levels of dependent loads are what it costs, so a thread takes Q chains (T apart, i.e. four tiles apart)
 // through them together -- counts and tile totals; scan; up to 12 staged records of its chains in one level, their
 // patterns in the next, then the stores -- and a workgroup covers T * Q chains: 256 workgroups per 32 MiB batch.
-template <int C, int T, int Q, bool PRIO>
+template <int C, int T, int Q>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lds_scatter_wide(LdsGroup g)   // (64 registers: two of its waves per SIMD next to a walk workgroup)
 {
 	constexpr uint32_t W = T / 64, kPer = T * Q, kSlots = 12;
 	static_assert(Q == 4 && T % (C * 64) == 0, "four chains a thread, whole tiles per slab");
-	// (the walk kernel next door is bound by instruction issue and has four waves per SIMD ready at any time: these
-	// waves, which mostly wait for memory, go first when they have something to issue)
-	if (PRIO)
-		__builtin_amdgcn_s_setprio(3);
+	// (s_setprio 3 here makes this kernel twice as fast next to a walk kernel and the job 9 % slower: the walk is
+	// bound by instruction issue, what these waves gain its waves lose, and more)
 	__shared__ uint32_t wtot[Q * W];
 	__shared__ uint32_t part[W], part_all[W];
 	const uint32_t nb = (g.n_chains + kPer - 1) / kPer;
@@ -871,7 +864,7 @@ int lds_walk_enqueue(const acm_dfa *d, const LdsJob *jobs, uint32_t count, hipSt
 	if (blocks > (uint32_t)d->num_cus)
 		blocks = (uint32_t)d->num_cus;
 	static const bool plain = getenv("ACM_LDS_NOASM") != nullptr;   // debugging aid: the compiler's version of the step
-	static const int sblock = getenv("ACM_LDS_SCATTER_BLOCK") ? atoi(getenv("ACM_LDS_SCATTER_BLOCK")) : kScatterBlockDefault;
+	static const int sblock = getenv("ACM_LDS_SCATTER_BLOCK") ? atoi(getenv("ACM_LDS_SCATTER_BLOCK")) : 0;
 	if (plain)
 		hipLaunchKernelGGL((k_lds_walk<C, false, 6>), dim3(blocks), dim3(kWalkBlock), d->lds_image_bytes, s, g);
 	else if (g.hb <= 16)
@@ -883,20 +876,10 @@ int lds_walk_enqueue(const acm_dfa *d, const LdsJob *jobs, uint32_t count, hipSt
 	if (after_walk2)
 		ACM_HIP_TRY(hipEventRecord(after_walk2, s));
 	auto sblocks = [&](uint32_t per) { return dim3(((g.n_chains + per - 1) / per) * count); };
-	if (sblock == 0)
-	{
-		static const bool prio = getenv("ACM_LDS_SCATTER_PRIO") ? atoi(getenv("ACM_LDS_SCATTER_PRIO")) != 0 : false;
-		if (prio)
-			hipLaunchKernelGGL((k_lds_scatter_wide<C, 512, 4, true>), sblocks(2048), dim3(512), 0, s, g);
-		else
-			hipLaunchKernelGGL((k_lds_scatter_wide<C, 512, 4, false>), sblocks(2048), dim3(512), 0, s, g);
-	}
-	else if (sblock == 1024)
+	if (sblock == 1024)   // debugging aid (ACM_LDS_SCATTER_BLOCK=1024): the plain scatter, a thread per chain
 		hipLaunchKernelGGL((k_lds_scatter<C, 1024>), sblocks(1024), dim3(1024), 0, s, g);
-	else if (sblock == 256)
-		hipLaunchKernelGGL((k_lds_scatter<C, 256>), sblocks(256), dim3(256), 0, s, g);
 	else
-		hipLaunchKernelGGL((k_lds_scatter<C, 512>), sblocks(512), dim3(512), 0, s, g);
+		hipLaunchKernelGGL((k_lds_scatter_wide<C, 512, 4>), sblocks(2048), dim3(512), 0, s, g);
 	ACM_HIP_TRY(hipGetLastError());
 	return ACM_OK;
 }

@@ -239,16 +239,6 @@ struct __attribute__((packed)) Unaligned8 {
 	uint64_t v;
 };
 
-// 8 text bytes at any position; bytes past the padded end read as zero
-__device__ __forceinline__ uint64_t load8(const SieveArgs &a, uint32_t pos)
-{
-	if (pos + 8 <= a.n_pad)
-		return ((const Unaligned8 *)(a.text + pos))->v;
-	if (pos >= a.n_pad)
-		return 0;
-	return *(const uint64_t *)(a.text + a.n_pad - 8) >> (8 * (pos - (a.n_pad - 8)));
-}
-
 // bytes sh .. sh+7 of the 16-byte string lo:hi
 __device__ __forceinline__ uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh)
 {
