@@ -611,10 +611,11 @@ def run_workload(ctx, wl, steps, warmup, repeats, ntexts, workers, verify, headl
                 "text_residency": residency,
                 "pipeline": path,
                 "workers": W,
-                "batches_in_flight": W * (G if (groups_apply and args.issue != "main") else 1),
+                "batches_in_flight": min(K, W * Geff),
                 "host_threads": W if pool is not None else 1,
                 "issue": args.issue,
-                "batches_per_launch_group": G if (groups_apply and args.issue != "main") else 1,
+                "batches_per_launch_group": Geff,      # what a launch really carries (a 20-step block on 3 workers: 7)
+                "max_launch_group": G if (groups_apply and args.issue != "main") else 1,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                 "parallelism": "text sharded %d-way (%s), DFA replicated" % (world, "strong" if strong else "weak"),
                 "gather": ("acm_gather_planes (own RCCL communicator)" if ctx.get("rccl_comm") is not None

@@ -136,8 +136,8 @@ bool emit(const Work &w, CompactTables &t, uint32_t lds_bytes)
 					target[a.fail[s]] = 1;
 			}
 		const std::vector<uint32_t> &order = a.bfs_order;
-		if (order.size() != n || target[0])
-			return false;
+		if (order.size() != n || target[0] || a.is_final_ref(0))
+			return false;   // (the root is id 0 and not final: what the walk starts in and what the scatter decodes codes by)
 		uint32_t next = 0;
 		for (int pass = 0; pass < 2; pass++) {
 			if (pass == 1)

@@ -1340,13 +1340,17 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 	}
 	uint32_t my_samples = al0.z, rows_all;
 	const uint32_t extra = PLAIN || tid == 0 ? 0u : al0.w & 0xFFFFu;   // (row 0 is the walker's: its word says nothing)
-	const uint32_t ord = block_exclusive<false>(tid < statics ? 1u + extra : 0u, lds, &rows_all);
-	if (tid < statics) {
-		s_ord[tid] = ord;
-		s_first[tid] = ord - tid;   // sub-rows of the blocks in front: the number of this block's first (k_sieve_check)
+	if constexpr (PLAIN) {
+		rows_all = statics;   // (row = thread: no order to work out)
+	} else {
+		const uint32_t ord = block_exclusive<false>(tid < statics ? 1u + extra : 0u, lds, &rows_all);
+		if (tid < statics) {
+			s_ord[tid] = ord;
+			s_first[tid] = ord - tid;   // sub-rows of the blocks in front: the number of this block's first (k_sieve_check)
+		}
+		if (tid == 0)
+			s_ord[statics] = rows_all;
 	}
-	if (tid == 0)
-		s_ord[statics] = rows_all;
 	if (blk == 0) {   // (a wave at a time: five hundred atomics on one LDS word would take longer than the copy below)
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1)
@@ -1409,8 +1413,10 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 		const uint32_t cell = cell_in + block_exclusive<false>(kept, lds, &all_cells);
 		s_base[tid] = cell;
 		s_drop[tid] = d;
-		s_slot[tid] = rr.slot;
-		s_lbase[tid] = rr.lbase;
+		if constexpr (!PLAIN) {
+			s_slot[tid] = rr.slot;
+			s_lbase[tid] = rr.lbase;
+		}
 		if (tid == 0)
 			s_base[kEmitBlock] = cell_in + all_cells;
 		__syncthreads();
@@ -1426,8 +1432,8 @@ __global__ __launch_bounds__(kEmitBlock) void k_sieve_emit(SieveGroup g)
 					hi = mid;
 			}
 			RowRef from;
-			from.slot = s_slot[lo];
-			from.lbase = s_lbase[lo];
+			from.slot = PLAIN ? lo : s_slot[lo];
+			from.lbase = PLAIN ? lo * a.cap : s_lbase[lo];
 			const uint2 rec = *hit_slot(a, from, s_drop[lo] + (c - s_base[lo]));
 			if (c + 2 < a.plane_capacity) {
 				a.pat_plane[1 + c] = (int32_t)rec.y;
