@@ -85,7 +85,8 @@ using acm_dev::agree16;
 
 constexpr int kBlock = 512;              // threads of a k_sieve workgroup
 constexpr int kWaves = kBlock / 64;
-constexpr uint32_t kTilesPerChecker = 8;   // tiles whose flagged samples one wave of k_sieve_check takes
+constexpr uint32_t kTilesPerChecker = 8;    // tiles whose flagged samples one wave of k_sieve_check takes when a batch is launched alone ...
+constexpr uint32_t kTilesPerCheckerWide = 16;   // ... and in a launch group (see k_sieve_check)
 constexpr int kCheckBlock = 64;            // threads of a k_sieve_check workgroup
 constexpr uint32_t kQ2Cap = 64 + 64 * 8;   // followers a checker queues: what a round leaves + 64 samples x 8 offsets
 constexpr uint32_t kMinTile = 1024;        // bytes; one 16-byte group per lane
@@ -1031,19 +1032,22 @@ __global__ __launch_bounds__(kBlock) void k_sieve(SieveGroup g)
 // -- and kHelperWaves that have none of their own -- takes sub-rows off the list until it is empty.
 // Nobody waits for anybody: a block's wave empties the list itself if no one else does.  One more
 // workgroup per batch walks the carried state and the tail.
+template <uint32_t TPC>
 struct BlockCounts {
-	uint32_t cum[kTilesPerChecker + 1];   // samples in front of each of the block's tiles (wave-uniform)
-	uint32_t mycount;                     // of the tile this lane looks at in the speculative round
-	uint2 spec;                           // that tile's sample for this lane
+	uint32_t cum[TPC + 1];   // samples in front of each of the block's tiles (wave-uniform)
+	uint32_t mycount;        // of the tile this lane looks at in the speculative round
+	uint2 spec;              // that tile's sample for this lane
 };
-constexpr uint32_t kSpecLanes = 64 / kTilesPerChecker;   // lanes (= samples) per tile in the speculative round
-static_assert(64 % kTilesPerChecker == 0 && kSampleHead >= kSpecLanes, "the speculative first round deals the lanes evenly");
+static_assert(64 % kTilesPerChecker == 0 && 64 % kTilesPerCheckerWide == 0 && kSampleHead >= 64 / kTilesPerChecker,
+    "the speculative first round deals the lanes evenly");
 
 // the counts of a block's tiles and, in the same load level, the first samples of each: when no tile has
-// more than its share of the lanes (nearly always) that is the first and only stage-1 round
-__device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, uint32_t lane, BlockCounts &bc)
+// more than its share of the lanes (with eight tiles: nearly always) that is the first and only stage-1 round
+template <uint32_t TPC>
+__device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, uint32_t lane, BlockCounts<TPC> &bc)
 {
-	const uint32_t tile0 = blk * kTilesPerChecker;
+	constexpr uint32_t kSpecLanes = 64 / TPC;   // lanes (= samples) per tile in the speculative round
+	const uint32_t tile0 = blk * TPC;
 	const uint32_t my_tile = tile0 + lane / kSpecLanes, my_idx = lane % kSpecLanes;
 	const bool tile_ok = my_tile < a.ntiles;
 	const uint32_t tile_c = tile_ok ? my_tile : tile0;
@@ -1051,7 +1055,7 @@ __device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, ui
 	bc.spec = a.shead[(size_t)tile_c * kSampleHead + my_idx];
 	bc.cum[0] = 0;
 #pragma unroll
-	for (uint32_t k = 0; k < kTilesPerChecker; k++)
+	for (uint32_t k = 0; k < TPC; k++)
 		bc.cum[k + 1] = bc.cum[k] + (uint32_t)__builtin_amdgcn_readlane((int)bc.mycount, (int)(k * kSpecLanes));
 }
 
@@ -1060,17 +1064,18 @@ __device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, ui
 // Returns the number of sub-rows the block has beyond its first.  (The counts are loaded in here, not handed in:
 // carried around the caller's loop they cost the kernel thirty registers.)
 // WHOLE: no sub-rows, the block is one row (no helper waves launched: cutting it up would only be bookkeeping).
-template <int W, bool WHOLE>
+template <int W, bool WHOLE, uint32_t TPC>
 __device__ __forceinline__ uint32_t check_subrow(const SieveArgs &a, uint32_t (*q2)[kQ2Cap], uint32_t lane, uint32_t blk, uint32_t j,
     uint32_t slot, unsigned long long *stamp)
 {
-	BlockCounts bc;
-	load_counts(a, blk, lane, bc);
-	const uint32_t tile0 = blk * kTilesPerChecker;
+	constexpr uint32_t kSpecLanes = 64 / TPC;
+	BlockCounts<TPC> bc;
+	load_counts<TPC>(a, blk, lane, bc);
+	const uint32_t tile0 = blk * TPC;
 	uint32_t dbg_rounds = 0, dbg_cands = 0, dbg_levels = 0;
 	Row t;
 	t.carry = t.count = t.first = t.last = t.akey = t.anode = t.gave_up = 0;
-	const uint32_t ns = bc.cum[kTilesPerChecker];
+	const uint32_t ns = bc.cum[TPC];
 	const uint32_t extras = !WHOLE && ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
 	const uint32_t lo = WHOLE ? 0u : j * a.subrow, hi = WHOLE ? ns : min(ns, lo + a.subrow);
 	t.samples = j == 0 ? ns : 0u;   // (in the row's summary: an atomic on one counter would be 512 waves' loads waiting for it)
@@ -1129,7 +1134,7 @@ __device__ __forceinline__ uint32_t check_subrow(const SieveArgs &a, uint32_t (*
 		const bool act = idx < hi;
 		uint32_t tslot = 0, before = 0;
 #pragma unroll
-		for (uint32_t k = 1; k < kTilesPerChecker; k++) {
+		for (uint32_t k = 1; k < TPC; k++) {
 			tslot += idx >= bc.cum[k] ? 1u : 0u;
 			before = idx >= bc.cum[k] ? bc.cum[k] : before;
 		}
@@ -1171,7 +1176,11 @@ __device__ __forceinline__ uint32_t check_subrow(const SieveArgs &a, uint32_t (*
 // HELPED: helper waves were launched (the last batches were sample-heavy).  Without them (the common case) every
 // block is one row and the kernel is a straight line: the loop of the helped kind costs 40 registers, and next to
 // two bulk workgroups a SIMD has 128 left for the checks of the other streams' batches.
-template <int W, bool HELPED>
+// TPC: tiles per block = per row.  8 when a batch is launched alone: the first stage-1 round then has the samples of
+// nearly every block in one load level, 36 us for a batch; 16 in a launch group of four or more: half the waves,
+// each with twice the lanes busy in the followers' levels -- the kernel is paced by waves x levels in the shadow
+// of the other streams' bulk kernels: 4.09 -> 4.36 TB/s (40 us for a batch alone; 32 tiles: 4.24 and 53).
+template <int W, bool HELPED, uint32_t TPC>
 __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint32_t helpers)
 {
 	__shared__ uint32_t q2[3][kQ2Cap];
@@ -1195,7 +1204,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 	if (stamp && lane == 0)
 		stamp[0] = __builtin_amdgcn_s_memrealtime();
 	if constexpr (!HELPED) {
-		(void)check_subrow<W, true>(a, q2, lane, blk, 0, blk + 1, stamp);
+		(void)check_subrow<W, true, TPC>(a, q2, lane, blk, 0, blk + 1, stamp);
 	} else {
 		// The sub-rows behind the first of every block are numbered through the batch in block order and dealt to
 		// the helper waves.  A lane takes eight neighbouring blocks (sixty-four tiles: the text has at most 4096),
@@ -1209,17 +1218,18 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 			uint32_t mine = 0;
 #pragma unroll
 			for (uint32_t i = 0; i < 8; i++) {
-				const uint32_t t0 = (lane * 8 + i) * kTilesPerChecker;
-				uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-				if (t0 < a.ntiles) {   // (the counts behind the last tile are whatever they are: masked below)
-					lo = sc[t0 / 4];
-					hi = sc[t0 / 4 + 1];
-				}
-				const uint32_t c[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+				const uint32_t t0 = (lane * 8 + i) * TPC;
 				uint32_t ns = 0;
 #pragma unroll
-				for (uint32_t k = 0; k < 8; k++)
-					ns += t0 + k < a.ntiles ? c[k] : 0u;
+				for (uint32_t q = 0; q < TPC / 4; q++) {
+					uint4 v = make_uint4(0, 0, 0, 0);
+					if (t0 + 4 * q < a.ntiles)   // (the counts behind the last tile are whatever they are: masked below)
+						v = sc[t0 / 4 + q];
+					const uint32_t c[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+					for (uint32_t k = 0; k < 4; k++)
+						ns += t0 + 4 * q + k < a.ntiles ? c[k] : 0u;
+				}
 				const uint32_t ex = ns > a.subrow ? (ns + a.subrow - 1) / a.subrow - 1 : 0u;
 				s_extra[i][lane] = ex;
 				s_first[i][lane] = mine;
@@ -1253,7 +1263,7 @@ __global__ __launch_bounds__(kCheckBlock) void k_sieve_check(SieveGroup g, uint3
 				tj = (uint32_t)__builtin_amdgcn_readlane((int)fk, src);
 				tslot = a.nrows + s0;
 			}
-			(void)check_subrow<W, false>(a, q2, lane, tb, tj, tslot, own ? stamp : nullptr);
+			(void)check_subrow<W, false, TPC>(a, q2, lane, tb, tj, tslot, own ? stamp : nullptr);
 			if (own)
 				return;
 		}
@@ -1490,19 +1500,19 @@ struct Geometry {
 // Nothing overflows: a tile's sample list has room for every sample of the tile, a row's hit list
 // for one hit per text position the followers of its tiles can reach (the shadow rule leaves at
 // most one per position).
-Geometry geometry_for(const acm_dfa *d, size_t n)
+Geometry geometry_for(const acm_dfa *d, size_t n, uint32_t tpc = kTilesPerChecker)
 {
 	Geometry g;
 	g.tile_bytes = kMinTile;
 	while ((n + g.tile_bytes - 1) / g.tile_bytes > kMaxTiles)
 		g.tile_bytes *= 2;
 	g.ntiles = (uint32_t)((n + g.tile_bytes - 1) / g.tile_bytes);
-	g.nrows = (g.ntiles + kTilesPerChecker - 1) / kTilesPerChecker + 1;
+	g.nrows = (g.ntiles + tpc - 1) / tpc + 1;
 	g.scap = g.tile_bytes / (d->sv_stride ? d->sv_stride : 1);
 	// sub-rows (k_sieve_check): a block has at most maxsub, each needs sub_k entries beyond its span
 	g.sub_k = d->max_pattern_len + (d->sv_stride ? d->sv_stride : 1) + 8;
-	const uint32_t maxsub = (kTilesPerChecker * g.scap + kSubRowMin - 1) / kSubRowMin;
-	g.cap = kTilesPerChecker * g.tile_bytes + maxsub * g.sub_k + 8;
+	const uint32_t maxsub = (tpc * g.scap + kSubRowMin - 1) / kSubRowMin;
+	g.cap = tpc * g.tile_bytes + maxsub * g.sub_k + 8;
 	g.max_extra = (uint32_t)(((size_t)g.ntiles * g.scap + kSubRowMin - 1) / kSubRowMin) + 1;
 	return g;
 }
@@ -1512,9 +1522,9 @@ Geometry geometry_for(const acm_dfa *d, size_t n)
 namespace acm {
 
 namespace {
-size_t workspace_for_exactly(const acm_dfa *d, size_t n)
+size_t workspace_for_tpc(const acm_dfa *d, size_t n, uint32_t tpc)
 {
-	const Geometry g = geometry_for(d, n);   // tile size and cap grow with the text, the tile count is bounded
+	const Geometry g = geometry_for(d, n, tpc);   // tile size and cap grow with the text, the tile count is bounded
 	size_t o = 0;
 	const size_t rows_max = (size_t)g.nrows + g.max_extra;
 	o += align_up(rows_max * kSummaryWords * 4, 256);
@@ -1525,6 +1535,10 @@ size_t workspace_for_exactly(const acm_dfa *d, size_t n)
 	o += align_up((size_t)kMaxTiles * 4, 256);
 	o += 256;
 	return o;
+}
+size_t workspace_for_exactly(const acm_dfa *d, size_t n)   // (either block size: which one a scan uses depends on how it is launched)
+{
+	return std::max(workspace_for_tpc(d, n, kTilesPerChecker), workspace_for_tpc(d, n, kTilesPerCheckerWide));
 }
 }  // namespace
 
@@ -1555,9 +1569,9 @@ int sparse_prepare(const acm_dfa *)
 
 namespace {
 // the shared part of a group's kernel arguments: tables, geometry for texts of n bytes, workspace layout
-void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g)
+void fill_common(const acm_dfa *d, size_t n, SieveGroup &grp, Geometry &g, uint32_t tpc)
 {
-	g = geometry_for(d, n);
+	g = geometry_for(d, n, tpc);
 	SieveArgs &a = grp.common;
 	a.bloom = d->d_sv_bloom;
 	a.bloom_log_words = d->sv_bloom_log_words;
@@ -1642,8 +1656,22 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 	SieveGroup grp;
 	memset(&grp, 0, sizeof(grp));
 	grp.count = count;
+	// Helper waves for the sub-rows of sample-heavy blocks only where the text is like that: the emit
+	// kernel leaves the batch's sample count in pinned host memory, and a launch whose stream's last batch
+	// had more than a flagged sample per 512 bytes gets them (a block is one row whatever it holds
+	// otherwise -- the first heavy batch after quiet ones is slow).  On quiet text thousands more
+	// workgroups per batch, each reading the batch's 4096 tile counts, cost a launch group of sixteen 20 us.
+	static const char *force = getenv("ACM_SIEVE_HELPERS");   // debugging aid: "0" never, anything else always
+	const uint32_t seen = d->h_giveups ? ((volatile uint32_t *)d->h_giveups)[1] : 0u;
+	const bool heavy = force ? force[0] != '0' : seen > n / kHeavyDivisor;
+	static const uint32_t helper_waves = getenv("ACM_SIEVE_HELPER_WAVES") ? (uint32_t)atoi(getenv("ACM_SIEVE_HELPER_WAVES")) : kHelperWaves;   // debugging aid
+	const uint32_t helpers = heavy ? helper_waves : 0u;
+	// blocks of 16 tiles for a launch group without helpers, of 8 otherwise (k_sieve_check)
+	static const char *force_tpc = getenv("ACM_SIEVE_TPC");   // debugging aid: 8 or 16 always
+	const uint32_t tpc = force_tpc ? (atoi(force_tpc) == 16 && !helpers ? kTilesPerCheckerWide : kTilesPerChecker)
+	                               : (!helpers && count >= 4 ? kTilesPerCheckerWide : kTilesPerChecker);
 	Geometry g;
-	fill_common(d, n, grp, g);
+	fill_common(d, n, grp, g, tpc);
 	for (uint32_t i = 0; i < count; i++)
 		fill_batch(jobs[i], grp.b[i]);
 	SieveArgs &a = grp.common;
@@ -1673,16 +1701,6 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		blocks = (uint32_t)d->num_cus;
 	// K2: a wave per kTilesPerChecker tiles, and one workgroup for the serial walks
 	const uint32_t cwaves = g.nrows - 1;
-	// Helper waves for the sub-rows of sample-heavy blocks only where the text is like that: the emit
-	// kernel leaves the batch's sample count in pinned host memory, and a launch whose stream's last batch
-	// had more than a flagged sample per 512 bytes gets them (the blocks' waves do their sub-rows
-	// themselves otherwise -- the first heavy batch after quiet ones is slow).  On quiet text 512 more
-	// workgroups per batch, each reading the batch's 4096 tile counts, cost a launch group of sixteen 20 us.
-	static const char *force = getenv("ACM_SIEVE_HELPERS");   // debugging aid: "0" never, anything else always
-	const uint32_t seen = d->h_giveups ? ((volatile uint32_t *)d->h_giveups)[1] : 0u;
-	const bool heavy = force ? force[0] != '0' : seen > n / kHeavyDivisor;
-	static const uint32_t helper_waves = getenv("ACM_SIEVE_HELPER_WAVES") ? (uint32_t)atoi(getenv("ACM_SIEVE_HELPER_WAVES")) : kHelperWaves;   // debugging aid
-	const uint32_t helpers = heavy ? helper_waves : 0u;
 	const uint32_t cblocks = (cwaves + 1 + helpers + 7u) & ~7u;   // (a multiple of 8 per batch: k_sieve_check)
 	uint32_t eblocks = 2;   // a power of two; each works out the whole prefix, more of them only for the copies
 	while (eblocks < 64 && ((size_t)eblocks << 22) < n)   // (a CU issues scattered 4-byte stores one a clock)
@@ -1719,9 +1737,11 @@ int sparse_group_enqueue(const acm_dfa *d, const SieveJob *jobs, uint32_t count,
 		ACM_HIP_TRY(hipEventRecord(after_sieve, s));
 	static const char *skip = getenv("ACM_SIEVE_SKIP");   // experiment (results are void): "c" no check kernel, "e" no emit kernel
 	const bool skip_check = skip && strchr(skip, 'c'), skip_emit = skip && strchr(skip, 'e');
-#define ACM_CHECK(W)                                                                                                       \
-	if (helpers) hipLaunchKernelGGL((k_sieve_check<W, true>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); \
-	else hipLaunchKernelGGL((k_sieve_check<W, false>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers)
+#define ACM_CHECK(W)                                                                                                                        \
+	if (helpers) hipLaunchKernelGGL((k_sieve_check<W, true, kTilesPerChecker>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers); \
+	else if (tpc == kTilesPerCheckerWide)                                                                                                       \
+		hipLaunchKernelGGL((k_sieve_check<W, false, kTilesPerCheckerWide>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers);     \
+	else hipLaunchKernelGGL((k_sieve_check<W, false, kTilesPerChecker>), dim3(cblocks * count), dim3(kCheckBlock), 0, s, grp, helpers)
 	if (!skip_check)
 	switch (d->sv_stride) {
 	case 8: ACM_CHECK(8); break;
