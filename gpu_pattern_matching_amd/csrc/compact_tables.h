@@ -3,8 +3,8 @@
 // A set of words over a small alphabet (the sentiment set: 15 704 states, 27 byte classes) has a
 // full DFA of 1 MB -- six times the LDS -- yet its rows are nearly all copies: the row of a trie
 // node is the row of its fail state with the node's own children written over it.  So only the
-// shallow states (and the few that branch) keep a full row; every other state is a 4-byte record
-// "one override, else look in THAT row", and the whole automaton -- every state the walk can be
+// shallow states (and the few that branch) keep a full row; every state has an 8-byte record
+// "two overrides, else look in THAT row", and the whole automaton -- every state the walk can be
 // in, final ones included -- fits the 160 KiB of a CU.  The walk kernel (lds_walk.hip) then never
 // leaves the LDS: no cold plane, no wave-uniform gather branch.  (160 KiB less 2 KiB: the few words of LDS a
 // scatter workgroup needs to run beside the walk.)
@@ -22,8 +22,9 @@
 // Which states keep a row: the root, every state with more than two transitions that neither its
 // nearest row nor its fail state's record explains, and -- shallow first, while the LDS has room --
 // states that would otherwise defer to their fail state's record (a second hop for the walk).
-// Compact ids: the non-final states in trie preorder (root = 0), then the final ones.  A row is found through
-// its state's record, not through the id.  (Every field is sized so that a step of the walk is nine vector
+// Compact ids: the non-final states in breadth-first order (root = 0), then the final ones; states that other
+// records defer to on even ids (compact_tables.cpp says why).  A row is found through its state's record, not
+// through the id.  (Every field is sized so that a step of the walk is nine vector
 // instructions: address = code << 3; cell address = next16 + 2*class in one add; targets are whole codes.)
 #pragma once
 

@@ -8,14 +8,16 @@
 //                  front of it: the state of an Aho-Corasick automaton only remembers the last L - 1
 //                  bytes, so from the chain's own first byte on the walk is the serial one (halo
 //                  mode, scan.hip).  Per byte: the class of the byte, the state's 8-byte record, the
-//                  row cell the record points at -- three LDS reads, no global memory, no branch --
-//                  and only where a lane's record defers to its fail state's (0.7 % of the steps on
-//                  the sentiment corpus) a second trip through a wave-uniform loop.  A transition into
-//                  a final state stores {state code, step} in the lane's own list of the tile's staging
-//                  area, lists of the 64 lanes interleaved so that the k-th records lie side by side.
-//   k_lds_scatter  per 1024 chains: scan of the counts on top of the totals of the tiles in front,
-//                  records copied to their final, position-ordered cells with the pattern looked up,
-//                  header and trailer cells.
+//                  row cell the record points at -- three LDS reads, no global memory, no branch, no
+//                  loop: a lane whose record defers to its fail state's (1 % of the steps on the
+//                  sentiment corpus) goes on in that state and takes the same byte again with the next
+//                  step (step2_asm).  A transition into a final state stores {state code, step} in the
+//                  lane's own list of the tile's staging area, lists of the 64 lanes interleaved so
+//                  that the k-th records lie side by side.
+//   k_lds_scatter_wide  per 2048 chains (512 threads x 4): scan of the counts on top of the totals of the
+//                  tiles in front, records copied to their final, position-ordered cells with the
+//                  pattern looked up, header and trailer cells.  Sized to run beside the NEXT stream's
+//                  walk kernel (64 registers, 192 B of LDS).
 // Both kernels take a GROUP of up to 16 batches of one size (acm_scan_batches_async): the image is
 // copied once, the launch boundaries are paid once.
 #include <hip/hip_runtime.h>
