@@ -1037,6 +1037,7 @@ struct BlockCounts {
 	uint32_t cum[TPC + 1];   // samples in front of each of the block's tiles (wave-uniform)
 	uint32_t mycount;        // of the tile this lane looks at in the speculative round
 	uint2 spec;              // that tile's sample for this lane
+	uint2 spec2;             // (16 tiles: four lanes per tile) the sample four further on: the lanes hold the tiles' first eight
 };
 static_assert(64 % kTilesPerChecker == 0 && 64 % kTilesPerCheckerWide == 0 && kSampleHead >= 64 / kTilesPerChecker,
     "the speculative first round deals the lanes evenly");
@@ -1053,6 +1054,7 @@ __device__ __forceinline__ void load_counts(const SieveArgs &a, uint32_t blk, ui
 	const uint32_t tile_c = tile_ok ? my_tile : tile0;
 	bc.mycount = tile_ok ? a.scount[tile_c] : 0u;
 	bc.spec = a.shead[(size_t)tile_c * kSampleHead + my_idx];
+	bc.spec2 = 2 * kSpecLanes <= kSampleHead ? a.shead[(size_t)tile_c * kSampleHead + my_idx + kSpecLanes] : make_uint2(0, 0);
 	bc.cum[0] = 0;
 #pragma unroll
 	for (uint32_t k = 0; k < TPC; k++)
@@ -1138,9 +1140,21 @@ __device__ __forceinline__ uint32_t check_subrow(const SieveArgs &a, uint32_t (*
 			tslot += idx >= bc.cum[k] ? 1u : 0u;
 			before = idx >= bc.cum[k] ? bc.cum[k] : before;
 		}
-		uint2 it = make_uint2(0, 0);
-		if (act)
-			it = *sample_slot(a, tile0 + tslot, idx - before);
+		// the first eight samples of every tile came with the counts (load_counts): from the lane that holds them,
+		// no load level; only what lies deeper in a tile's list is fetched
+		const uint32_t kk = idx - before;
+		const int src = (int)(tslot * kSpecLanes + kk % kSpecLanes);
+		uint2 it = make_uint2((uint32_t)__shfl((int)bc.spec.x, src, 64), (uint32_t)__shfl((int)bc.spec.y, src, 64));
+		if (2 * kSpecLanes <= kSampleHead) {
+			const uint2 it2 = make_uint2((uint32_t)__shfl((int)bc.spec2.x, src, 64), (uint32_t)__shfl((int)bc.spec2.y, src, 64));
+			if (kk >= kSpecLanes)
+				it = it2;
+		}
+		constexpr uint32_t kHeld = 2 * kSpecLanes <= kSampleHead ? 2 * kSpecLanes : kSpecLanes;
+		if (!act)
+			it = make_uint2(0, 0);
+		else if (kk >= kHeld)
+			it = *sample_slot(a, tile0 + tslot, kk);
 		if (!placed) {
 			// (hits of this sub-row lie at or behind its first sample's position less W, one per position:
 			// the span of its samples + the longest pattern + W entries are enough, sub_k allows for that)
