@@ -553,6 +553,52 @@ def test_grouped_batches(gpu, group):
     m.close()
 
 
+def test_workspaces_reused_across_block_sizes(gpu):
+    """The check kernel takes blocks of 16 tiles in a launch group of four or more batches and of 8 when a batch is
+    launched alone: the rows of a workspace are laid out differently by the two.  The same workspaces used one way,
+    the other and back give the planes of scanning each text alone every time."""
+    pats = synth.load_hex_patterns(os.path.join(orc.DATA, "clamav", "15000.txt"), 400)
+    a, o = build(pats)
+    n = (1 << 20) + 8
+    m = Matcher(a, 0, max_text=n)
+    assert m.set_mode("sparse") == "sparse"
+    assert m.set_max_group(16) == 16
+    rng = np.random.default_rng(99)
+    texts = []
+    for k in range(5):
+        t = rng.integers(0, 256, size=n, dtype=np.uint8)
+        for _ in range(200 + 100 * k):
+            p = np.frombuffer(pats[int(rng.integers(len(pats)))], dtype=np.uint8)
+            at = int(rng.integers(0, n - p.size))
+            t[at:at + p.size] = p
+        texts.append(t)
+    exp = [o.scan(t) for t in texts]
+    ws_bytes = m.lib.acm_scan_workspace_bytes(m.dfa, n)
+    cap = 1 << 14
+    d_texts = [DeviceArray.from_numpy(t) for t in texts]
+    wss = [DeviceArray(ws_bytes) for _ in range(5)]
+    planes = [(DeviceArray(cap * 4), DeviceArray(cap * 4)) for _ in range(5)]
+
+    def batch(k, w):
+        return m.make_batch(d_texts[k], n, m.stream, planes[k][0], planes[k][1], cap, (wss[w], ws_bytes))
+
+    def check(ks):
+        for k in ks:
+            assert_same(_planes(planes[k][0], planes[k][1], cap, m.stream), exp[k])
+            planes[k][0].fill(0, stream=m.stream)
+
+    m.enqueue_many([batch(k, k) for k in range(5)])                 # one group of five: blocks of 16 tiles
+    check(range(5))
+    for k in range(5):                                              # each alone, on ANOTHER batch's workspace: blocks of 8
+        m.enqueue(batch(k, (k + 2) % 5))
+        check([k])
+    m.enqueue_many([batch(k, (k + 1) % 5) for k in range(4)])       # a group of four again
+    check(range(4))
+    m.enqueue_many([batch(k, k) for k in range(3)])                 # a group of three: blocks of 8
+    check(range(3))
+    m.close()
+
+
 def test_grouped_batches_large_tiles(gpu):
     """A launch group of texts large enough for tiles of several sub-blocks (40 MiB + 3: 16 KiB tiles, the
     bulk kernel's waves go through two sub-blocks per tile and ten tiles per batch), length not a
