@@ -324,14 +324,17 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		so0[c] = so[c] = ((uint32_t)c * (kChainBytes * 64) + lane) * 4;   // byte offset into the tile's staging area
 		// (the text's very first chain has no halo: its halo groups read the start of the text instead, and
 		// what the walk makes of them is thrown away below)
+		// (a chain behind the last of the text -- the text's last tile, when the chains are not a multiple of the
+		// tile -- walks the text's last bytes instead; what it finds stays in the staging area, nobody counts it)
+		const int32_t gl = (int32_t)(g.n >> 4) - 1;   // the last whole group of the text
 		const int32_t g0 = (int32_t)(base >> 4) - (int32_t)hg;
-		p0[c] = text16[max(g0, 0)];
-		p1[c] = text16[max(g0 + 1, 0)];
-		p2[c] = text16[g0 + 2];
-		p3[c] = text16[g0 + 3];
-		p4[c] = groups > 4 ? text16[g0 + 4] : make_uint4(0, 0, 0, 0);
+		p0[c] = text16[min(max(g0, 0), gl)];
+		p1[c] = text16[min(max(g0 + 1, 0), gl)];
+		p2[c] = text16[min(g0 + 2, gl)];
+		p3[c] = text16[min(g0 + 3, gl)];
+		p4[c] = groups > 4 ? text16[min(g0 + 4, gl)] : make_uint4(0, 0, 0, 0);
 		if constexpr (NG > 5)
-			p5[c] = groups > 5 ? text16[g0 + 5] : make_uint4(0, 0, 0, 0);
+			p5[c] = groups > 5 ? text16[min(g0 + 5, gl)] : make_uint4(0, 0, 0, 0);
 	}
 	static_assert(kMaxHaloGroups == 2, "the first two groups may be halo");
 #define ACM_PICK(gi)                                                                     \
@@ -384,10 +387,12 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 #pragma unroll
 	for (int c = 0; c < C; c++) {
 		const uint32_t k = (so[c] - so0[c]) >> 8;
-		b.cnt[chain[c]] = (uint8_t)k;   // (a whole tile: every chain exists)
-		total += k;
-		if (chain[c] == g.n_chains - 1)
-			b.misc[0] = e[c] & 0xFFFFu;
+		if (chain[c] < g.n_chains) {
+			b.cnt[chain[c]] = (uint8_t)k;
+			total += k;
+			if (chain[c] == g.n_chains - 1)
+				b.misc[0] = e[c] & 0xFFFFu;
+		}
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1)
@@ -521,14 +526,16 @@ __global__ __launch_bounds__(kWalkBlock) void k_lds_walk(LdsGroup g)
 		const uint32_t bi = t / g.n_tiles, wt = t - bi * g.n_tiles;
 		const LdsBatch &b = g.b[bi];
 		const uint64_t first = (uint64_t)wt * tile_bytes;
-		const bool whole = first + tile_bytes <= g.n && first >= b.drop_before;
+		// every chain of the tile that exists is whole (a text of whole chains may end inside the tile: the chains
+		// behind its end then walk for nothing), no shard halo in it
+		const bool whole = (first + tile_bytes <= g.n || (g.n & (kChainBytes - 1)) == 0) && first >= b.drop_before;
 		if constexpr (ASM && C == 2) {
 			if (whole)
 				walk_tile_fast<NG>(g, b, lds, wt, lane);   // (copes with the text's first chain itself)
 			else
 				walk_tile<C, true, NG>(g, b, lds, wt, lane);
 		} else {
-			if (whole && first >= g.hb)
+			if (first + tile_bytes <= g.n && first >= b.drop_before && first >= g.hb)
 				walk_tile<C, false, NG>(g, b, lds, wt, lane);
 			else
 				walk_tile<C, true, NG>(g, b, lds, wt, lane);
