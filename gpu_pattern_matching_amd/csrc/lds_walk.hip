@@ -326,7 +326,7 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 		// what the walk makes of them is thrown away below)
 		// (a chain behind the last of the text -- the text's last tile, when the chains are not a multiple of the
 		// tile -- walks the text's last bytes instead; what it finds stays in the staging area, nobody counts it)
-		const int32_t gl = (int32_t)(g.n >> 4) - 1;   // the last whole group of the text
+		const int32_t gl = (int32_t)((g.n + 15) >> 4) - 1;   // the last group of the text (whole or not: the buffer is padded to 16 bytes)
 		const int32_t g0 = (int32_t)(base >> 4) - (int32_t)hg;
 		p0[c] = text16[min(max(g0, 0), gl)];
 		p1[c] = text16[min(max(g0 + 1, 0), gl)];
@@ -386,10 +386,26 @@ __device__ __forceinline__ void walk_tile_fast(const LdsGroup &g, const LdsBatch
 	uint32_t total = 0;
 #pragma unroll
 	for (int c = 0; c < C; c++) {
-		const uint32_t k = (so[c] - so0[c]) >> 8;
+		const uint32_t base = chain[c] << kLogChain;
+		if (chain[c] < g.n_chains && base + kChainBytes > g.n) {
+			// The chain the text ends inside (one lane of one wave per batch): the written-out walk took bytes
+			// behind the end for text.  Once more by the book, byte by byte, over what there is.
+			const uint32_t from = base > hb ? base - hb : 0u;
+			uint32_t st = base > hb ? k.root : (b.init_ptr ? *b.init_ptr : b.init_code);
+			so[c] = so0[c];
+			for (uint32_t x = from; x < g.n; x++) {
+				st = next_code(lds, k.off_rec, st, b.text[x]);
+				if (x >= base && st >= k.fin) {
+					*(uint32_t *)((char *)stage + so[c]) = st | ((x - base) << 16);
+					so[c] += 256;
+				}
+			}
+			e[c] = st;
+		}
+		const uint32_t kcount = (so[c] - so0[c]) >> 8;
 		if (chain[c] < g.n_chains) {
-			b.cnt[chain[c]] = (uint8_t)k;
-			total += k;
+			b.cnt[chain[c]] = (uint8_t)kcount;
+			total += kcount;
 			if (chain[c] == g.n_chains - 1)
 				b.misc[0] = e[c] & 0xFFFFu;
 		}
@@ -526,9 +542,8 @@ __global__ __launch_bounds__(kWalkBlock) void k_lds_walk(LdsGroup g)
 		const uint32_t bi = t / g.n_tiles, wt = t - bi * g.n_tiles;
 		const LdsBatch &b = g.b[bi];
 		const uint64_t first = (uint64_t)wt * tile_bytes;
-		// every chain of the tile that exists is whole (a text of whole chains may end inside the tile: the chains
-		// behind its end then walk for nothing), no shard halo in it
-		const bool whole = (first + tile_bytes <= g.n || (g.n & (kChainBytes - 1)) == 0) && first >= b.drop_before;
+		// no shard halo in the tile (its records in front of drop_before are to be dropped: the generic walk)
+		const bool whole = first >= b.drop_before;   // (the text's end inside the tile: walk_tile_fast copes)
 		if constexpr (ASM && C == 2) {
 			if (whole)
 				walk_tile_fast<NG>(g, b, lds, wt, lane);   // (copes with the text's first chain itself)
