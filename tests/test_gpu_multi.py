@@ -102,21 +102,21 @@ def test_bench_collective_path_at_world_size_one(gpu, gather):
     assert rec["config"]["gather"].startswith("acm_gather_planes" if gather == "abi" else "torch")
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_rehearsal(gpu, scaling):
+@pytest.mark.parametrize("ranks,scaling", [(2, "weak"), (2, "strong"), (4, "weak")])
+def test_bench_ranks_rehearsal(gpu, ranks, scaling):
     """Two ranks of bench.py on the one GPU (ACM_BENCH_BACKEND=gloo: both on cuda:0, the gather goes
     through the host): shard plan, halo, offset shift, merged parity against the oracle's scan of
     the whole logical text -- the multi-rank logic of the driver's N > 1 runs, minus RCCL (which
     the world-size-1 tests above exercise)."""
     env = dict(os.environ, ACM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29541 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "16", "--warmup", "4",
            "--repeats", "2", "--texts", "2", "--scaling", scaling]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["scaling"] == scaling
+    assert rec["n_gpus"] == ranks and rec["scaling"] == scaling
     assert rec["parity"].startswith("bit-exact"), rec["parity"]
-    want = (32 << 20) * (2 if scaling == "weak" else 1)
+    want = (32 << 20) * (ranks if scaling == "weak" else 1)
     assert rec["config"]["text_bytes_per_step"] == want
