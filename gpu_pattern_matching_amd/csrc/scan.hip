@@ -1395,6 +1395,15 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 			want *= 2;
 		if (d->use_halo && C == 4 && hb > 0 && hb <= S && want > S && want <= 256 && (size_t)want * lanes <= 2 * n)
 			S = want;
+		// speculative mode (patterns longer than a chain): a chain's look-back window is ceil(L / S) chains, and
+		// it is the probe and resolve kernels' slowest lanes -- chains of dependent loads through that window --
+		// that those kernels take as long as.  Chains of a third of the longest pattern: half the chains of the
+		// same text at 32 MiB, i.e. half of every CU's lanes idle in the walk kernel -- which batches in flight
+		// side by side fill (ClamAV signatures, 3 streams: 635 instead of 489 GB/s; a batch alone 111 instead of
+		// 98 us).  Large texts only: a small one is short of chains as it is.
+		if (!(d->use_halo && hb <= S) && n >= ((size_t)16 << 20))
+			while (S < 256 && (d->max_pattern_len + S - 1) / S > 3)
+				S *= 2;
 	}
 	uint32_t logS = 0;
 	while ((1u << logS) < S)
