@@ -342,6 +342,8 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const uint16_t *hot
 			p2[c] = fetch(c, 2);
 			p3[c] = fetch(c, 3);
 			p4[c] = fetch(c, 4);
+			if (!HALO)   // speculative mode: the class of the chain's first byte, for the tile epilogue
+				fb[c] = CLS ? (uint32_t)clsmap[p0[c].x & 0xFFu] : p0[c].x & 0xFFu;
 		}
 	}
 	for (uint32_t g = 0; g < groups; g++) {
@@ -451,7 +453,10 @@ __global__ __launch_bounds__(kBlock1) void k_spec_walk(ScanArgs a)
 // Halo mode with the text loaded up front (walk_tile, PRE): the registers that takes are there for
 // workgroups of 8 waves; with chains of 64 bytes a 32 MiB text has a tile per wave of them anyway.
 constexpr int kBlockPre = 768;
-template <bool CLS>
+// HALO = false: the speculative mode's chains loaded up front the same way (chains of up to 80 bytes; with the
+// 64-byte chains long patterns get, a lane's four 16-byte loads per chain at a stride of one chain fetched every
+// line of the text several times: 182 MB counted for a 32 MiB text).
+template <bool CLS, bool HALO = true>
 __global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
@@ -477,9 +482,9 @@ __global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
 	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
 		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n && (uint64_t)wt * tile_bytes >= a.halo_bytes;
 		if (full)
-			walk_tile<4, false, CLS, true, true>(a, hot, clsmap, wt, lane);
+			walk_tile<4, false, CLS, HALO, true>(a, hot, clsmap, wt, lane);
 		else
-			walk_tile<4, true, CLS, true, true>(a, hot, clsmap, wt, lane);
+			walk_tile<4, true, CLS, HALO, true>(a, hot, clsmap, wt, lane);
 	}
 }
 
@@ -893,14 +898,21 @@ int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
 	if (blocks > (uint32_t)num_cus)
 		blocks = (uint32_t)num_cus;
-	if (a.halo_mode && C == 4 && a.halo_pre) {
+	if (C == 4 && a.halo_pre) {
 		uint32_t pblocks = (a.n_tiles + kBlockPre / 64 - 1) / (kBlockPre / 64);
 		if (pblocks > (uint32_t)num_cus)
 			pblocks = (uint32_t)num_cus;
-		if (a.ls == 8)
-			hipLaunchKernelGGL(k_halo_walk<false>, dim3(pblocks), dim3(kBlockPre), lds, s, a);
-		else
-			hipLaunchKernelGGL(k_halo_walk<true>, dim3(pblocks), dim3(kBlockPre), lds, s, a);
+		if (a.halo_mode) {
+			if (a.ls == 8)
+				hipLaunchKernelGGL((k_halo_walk<false, true>), dim3(pblocks), dim3(kBlockPre), lds, s, a);
+			else
+				hipLaunchKernelGGL((k_halo_walk<true, true>), dim3(pblocks), dim3(kBlockPre), lds, s, a);
+		} else {
+			if (a.ls == 8)
+				hipLaunchKernelGGL((k_halo_walk<false, false>), dim3(pblocks), dim3(kBlockPre), lds, s, a);
+			else
+				hipLaunchKernelGGL((k_halo_walk<true, false>), dim3(pblocks), dim3(kBlockPre), lds, s, a);
+		}
 	} else if (a.halo_mode && C == 4) {
 		if (a.ls == 8)
 			hipLaunchKernelGGL((k_spec_walk<4, false, true>), dim3(blocks), dim3(kBlock1), lds, s, a);
@@ -1192,7 +1204,8 @@ int scan_prepare(const acm_dfa *)
 	const void *walks[] = { (const void *)k_spec_walk<4, false, false>, (const void *)k_spec_walk<4, true, false>,
 		(const void *)k_spec_walk<2, false, false>, (const void *)k_spec_walk<2, true, false>,
 		(const void *)k_spec_walk<4, false, true>, (const void *)k_spec_walk<4, true, true>,
-		(const void *)k_halo_walk<false>, (const void *)k_halo_walk<true> };
+		(const void *)k_halo_walk<false, true>, (const void *)k_halo_walk<true, true>,
+		(const void *)k_halo_walk<false, false>, (const void *)k_halo_walk<true, false> };
 	for (const void *k : walks)
 		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(acm::kHotBytes + 256)));
 	return ACM_OK;
@@ -1444,6 +1457,8 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 		a.halo_mode = (d->use_halo && C == 4 && hb <= S) ? 1u : 0u;
 		a.halo_bytes = a.halo_mode ? hb : 0u;
 		a.halo_pre = (a.halo_mode && ((S + hb) >> 4) <= (uint32_t)kPreGroups && d->use_preload) ? 1u : 0u;
+		if (!a.halo_mode && C == 4 && S == 64 && d->use_preload)
+			a.halo_pre = 1u;   // (speculative mode, chains of 64 bytes: k_halo_walk<CLS, false>)
 	}
 	a.drop_before = (uint32_t)halo;
 	a.off_shift = (int32_t)offset_shift;
