@@ -456,8 +456,10 @@ constexpr int kBlockPre = 768;
 // HALO = false: the speculative mode's chains loaded up front the same way (chains of up to 80 bytes; with the
 // 64-byte chains long patterns get, a lane's four 16-byte loads per chain at a stride of one chain fetched every
 // line of the text several times: 182 MB counted for a 32 MiB text).
-template <bool CLS, bool HALO = true>
-__global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
+// C = 2, BLOCK = 1024 (speculative mode): 16 waves of two chains per lane -- 512 Ki chains a round, which is what a
+// 32 MiB text has at 64 bytes a chain: every lane busy, where 12 waves x 4 chains leave a third of them without work.
+template <bool CLS, bool HALO = true, int C = 4, int BLOCK = kBlockPre>
+__global__ __launch_bounds__(BLOCK) void k_halo_walk(ScanArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint16_t hot[];
 	uint8_t *clsmap = (uint8_t *)hot + acm::kHotBytes;
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
 		uint4 *dst = (uint4 *)hot;
 		const uint32_t n16 = ((a.H << a.ls) + 7) >> 3;
 		const uint32_t rot = n16 ? (blockIdx.x * 1021u) % n16 : 0u;
-		for (uint32_t i = threadIdx.x; i < n16; i += kBlockPre) {
+		for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) {
 			uint32_t j = i + rot;
 			j = j >= n16 ? j - n16 : j;
 			dst[j] = src[j];
@@ -476,15 +478,15 @@ __global__ __launch_bounds__(kBlockPre) void k_halo_walk(ScanArgs a)
 	}
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = blockIdx.x * (kBlockPre / 64) + (threadIdx.x >> 6);
-	const uint32_t nwaves = gridDim.x * (kBlockPre / 64);
-	const uint32_t tile_bytes = (4 * 64u) << a.logS;
+	const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+	const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+	const uint32_t tile_bytes = ((uint32_t)C * 64u) << a.logS;
 	for (uint32_t wt = wave; wt < a.n_tiles; wt += nwaves) {
 		const bool full = (uint64_t)(wt + 1) * tile_bytes <= a.n && (uint64_t)wt * tile_bytes >= a.halo_bytes;
 		if (full)
-			walk_tile<4, false, CLS, HALO, true>(a, hot, clsmap, wt, lane);
+			walk_tile<C, false, CLS, HALO, true>(a, hot, clsmap, wt, lane);
 		else
-			walk_tile<4, true, CLS, HALO, true>(a, hot, clsmap, wt, lane);
+			walk_tile<C, true, CLS, HALO, true>(a, hot, clsmap, wt, lane);
 	}
 }
 
@@ -898,7 +900,15 @@ int launch_spec_walk(const ScanArgs &a, int num_cus, hipStream_t s)
 	uint32_t blocks = (a.n_tiles + kWaves1 - 1) / kWaves1;
 	if (blocks > (uint32_t)num_cus)
 		blocks = (uint32_t)num_cus;
-	if (C == 4 && a.halo_pre) {
+	if (C == 2 && a.halo_pre && !a.halo_mode) {   // (speculative mode, 64-byte chains: 16 waves of two chains per lane)
+		uint32_t pblocks = (a.n_tiles + 1024 / 64 - 1) / (1024 / 64);
+		if (pblocks > (uint32_t)num_cus)
+			pblocks = (uint32_t)num_cus;
+		if (a.ls == 8)
+			hipLaunchKernelGGL((k_halo_walk<false, false, 2, 1024>), dim3(pblocks), dim3(1024), lds, s, a);
+		else
+			hipLaunchKernelGGL((k_halo_walk<true, false, 2, 1024>), dim3(pblocks), dim3(1024), lds, s, a);
+	} else if (C == 4 && a.halo_pre) {
 		uint32_t pblocks = (a.n_tiles + kBlockPre / 64 - 1) / (kBlockPre / 64);
 		if (pblocks > (uint32_t)num_cus)
 			pblocks = (uint32_t)num_cus;
@@ -1205,7 +1215,8 @@ int scan_prepare(const acm_dfa *)
 		(const void *)k_spec_walk<2, false, false>, (const void *)k_spec_walk<2, true, false>,
 		(const void *)k_spec_walk<4, false, true>, (const void *)k_spec_walk<4, true, true>,
 		(const void *)k_halo_walk<false, true>, (const void *)k_halo_walk<true, true>,
-		(const void *)k_halo_walk<false, false>, (const void *)k_halo_walk<true, false> };
+		(const void *)k_halo_walk<false, false>, (const void *)k_halo_walk<true, false>,
+		(const void *)k_halo_walk<false, false, 2, 1024>, (const void *)k_halo_walk<true, false, 2, 1024> };
 	for (const void *k : walks)
 		ACM_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(acm::kHotBytes + 256)));
 	return ACM_OK;
@@ -1392,8 +1403,9 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 
 	// geometry: enough chains to give every lane of every CU work, chains
 	// as long as that allows (longer chains = fewer look-back steps)
-	const int C = d->chains_per_lane == 2 ? 2 : 4;
+	int C = d->chains_per_lane == 2 ? 2 : 4;
 	uint32_t S = (uint32_t)d->chain_bytes;
+	bool wide_pre = false;   // speculative mode with 64-byte chains: two chains per lane, 16 waves per CU, text loaded up front
 	if (S == 0) {
 		const size_t lanes = (size_t)d->num_cus * kBlock1 * C;
 		S = 16;
@@ -1414,9 +1426,15 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 		// same text at 32 MiB, i.e. half of every CU's lanes idle in the walk kernel -- which batches in flight
 		// side by side fill (ClamAV signatures, 3 streams: 635 instead of 489 GB/s; a batch alone 111 instead of
 		// 98 us).  Large texts only: a small one is short of chains as it is.
-		if (!(d->use_halo && hb <= S) && n >= ((size_t)16 << 20))
+		if (!(d->use_halo && hb <= S) && n >= ((size_t)16 << 20)) {
 			while (S < 256 && (d->max_pattern_len + S - 1) / S > 3)
 				S *= 2;
+			static const bool no_wide = getenv("ACM_SCAN_NO_WIDE_PRE") != nullptr;   // debugging aid
+			if (S == 64 && C == 4 && d->use_preload && !no_wide) {
+				wide_pre = true;
+				C = 2;
+			}
+		}
 	}
 	uint32_t logS = 0;
 	while ((1u << logS) < S)
@@ -1457,8 +1475,8 @@ int enqueue_batch(const acm_dfa *d, const acm_scan_batch *batch, bool sparse, De
 		a.halo_mode = (d->use_halo && C == 4 && hb <= S) ? 1u : 0u;
 		a.halo_bytes = a.halo_mode ? hb : 0u;
 		a.halo_pre = (a.halo_mode && ((S + hb) >> 4) <= (uint32_t)kPreGroups && d->use_preload) ? 1u : 0u;
-		if (!a.halo_mode && C == 4 && S == 64 && d->use_preload)
-			a.halo_pre = 1u;   // (speculative mode, chains of 64 bytes: k_halo_walk<CLS, false>)
+		if (!a.halo_mode && S == 64 && d->use_preload && (C == 4 || wide_pre))
+			a.halo_pre = 1u;   // (speculative mode, chains of 64 bytes: k_halo_walk<CLS, false, ...>)
 	}
 	a.drop_before = (uint32_t)halo;
 	a.off_shift = (int32_t)offset_shift;
