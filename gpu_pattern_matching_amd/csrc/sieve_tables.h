@@ -54,10 +54,14 @@ ACM_HD uint32_t sieve_bloom_block(uint32_t gram, uint32_t more, uint32_t log_wor
 {
 	return (mul24(gram, kSieveMulA) + mul24(more, kSieveMulE)) >> (33 - log_words);
 }
+// the key's four bits: two in each 32-bit half of its block, so that the bulk kernel tests them with four 32-bit
+// shifts (whose count field is five bits wide: no masks) instead of four 64-bit ones
 ACM_HD uint64_t sieve_bloom_bits(uint32_t gram, uint32_t more)
 {
 	const uint32_t p = mul24(gram, kSieveMulB) + mul24(more, kSieveMulF);
-	return (1ull << (p >> 26)) | (1ull << ((p >> 20) & 63)) | (1ull << ((p >> 14) & 63)) | (1ull << ((p >> 8) & 63));
+	const uint32_t lo = (1u << (p >> 27)) | (1u << ((p >> 22) & 31));
+	const uint32_t hi = (1u << ((p >> 17) & 31)) | (1u << ((p >> 12) & 31));
+	return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // ---- gram table: buckets of four {gram | offset mask << 24}, 0 = empty -------

@@ -256,7 +256,9 @@ __device__ __forceinline__ uint64_t bloom_block(const uint32_t *bloom, uint32_t 
 __device__ __forceinline__ uint32_t bloom_test(uint64_t w, uint32_t gram, uint32_t more)
 {
 	const uint32_t p = acm::mul24(gram, acm::kSieveMulB) + acm::mul24(more, acm::kSieveMulF);
-	return (uint32_t)((w >> (p >> 26)) & (w >> ((p >> 20) & 63)) & (w >> ((p >> 14) & 63)) & (w >> ((p >> 8) & 63))) & 1u;
+	const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+	// (a 32-bit shift takes the low five bits of its count: sieve_bloom_bits' fields need no masks)
+	return ((lo >> ((p >> 27) & 31)) & (lo >> ((p >> 22) & 31)) & (hi >> ((p >> 17) & 31)) & (hi >> ((p >> 12) & 31))) & 1u;
 }
 
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
